@@ -1,0 +1,182 @@
+/*
+ * kvzip_hip.h — C ABI of the MI355X (gfx950) KV-eviction hot path.
+ *
+ * This is the drop-in boundary for the path named by BASELINE.json:north_star:
+ *   KV importance scoring -> threshold / top-k selection -> KV compaction ->
+ *   O(1) append -> variable-length post-prune attention.
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers plus sizes, an
+ * explicit HIP stream as its last argument, never allocates, never synchronises
+ * the device and returns 0 on success or a negative KVZ_E* code (the message is
+ * available from kvz_last_error()).  The caller owns every buffer.
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths are relative to snu-mllab/KVzip @ 2026-03-13).
+ */
+#ifndef KVZIP_HIP_H
+#define KVZIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVZ_ABI_VERSION 1
+
+/* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
+#define KVZ_F16 0
+#define KVZ_BF16 1
+
+/* error codes */
+#define KVZ_OK 0
+#define KVZ_EINVAL (-1)   /* bad argument (shape, dtype, alignment, null pointer) */
+#define KVZ_EWORKSPACE (-2) /* workspace too small */
+#define KVZ_ELAUNCH (-3)  /* HIP launch / runtime error */
+#define KVZ_EUNSUPPORTED (-4) /* unsupported head_dim / group size */
+
+typedef void* kvz_stream_t; /* hipStream_t */
+
+int kvz_abi_version(void);
+/* thread-local, NUL-terminated description of the last non-zero return */
+const char* kvz_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * a1  KV importance scoring          reference: attention/score.py:36-65
+ *     (+ causal mask                 reference: attention/score.py:67-85)
+ *
+ * For one layer and one scoring chunk, for every KV head h:
+ *   keys  = K[h, 0:sink] ++ K[h, start:end] ++ K[h, klen-q_len:klen]
+ *   A     = half( half(Q_h . keys^T  [fp32 accumulate]) / float(sqrt(D)) )
+ *   A[:, :, -q_len:] causally masked (key j of the repeat block visible to query i iff j <= i)
+ *   P     = softmax(A, dim=keys)  (fp32 internally, rounded once to half)
+ *   out[h, 0:end-start] = max over (group g, query i) of P[g, i, sink:sink+end-start]
+ *
+ * q   : [Hkv*G, q_len, D]   rows contiguous (D), head stride q_head_stride elements
+ * k   : [Hkv, klen, D]      rows contiguous (D), head stride k_head_stride elements
+ * out : [Hkv, end-start]    half (same dtype as q/k), head stride out_head_stride elements
+ * ws  : kvz_score_workspace_bytes(...) bytes of device scratch
+ * D in {64, 128}.
+ * ------------------------------------------------------------------------- */
+size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m);
+int kvz_score_chunk(const void* q, int64_t q_head_stride,
+                    const void* k, int64_t k_head_stride, int klen,
+                    int sink, int start, int end, int q_len,
+                    int Hkv, int G, int D, int dtype,
+                    void* out, int64_t out_head_stride,
+                    void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * a4  global-threshold selection     reference: attention/score.py:88-102
+ *
+ *   flat   = scores viewed as n values (any leading shape)
+ *   idx    = max((int64)((double)n * ratio) - 1, 0)
+ *   thres  = idx-th largest value (0-based, duplicates counted)
+ *   valid  = scores > thres            (strict: ties at thres are evicted)
+ *   ratio >= 1  ->  valid all ones, thres = 0
+ *
+ * scores       : n half values
+ * valid_out    : n bytes (0/1), same flat order
+ * row_counts   : optional int32[n / row_len]  number of valid entries per row of row_len
+ * result_dev   : float[2] on device: {thres, (float)kept_total}; int64 kept at result_dev64[0]
+ * ws           : kvz_select_workspace_bytes() bytes
+ * ------------------------------------------------------------------------- */
+size_t kvz_select_workspace_bytes(void);
+int kvz_select_threshold(const void* scores, int64_t n, double ratio, int dtype,
+                         uint8_t* valid_out,
+                         int64_t row_len, int32_t* row_counts,
+                         float* thres_dev, int64_t* kept_dev,
+                         void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * a5  per-(layer,head) top-k         reference: attention/score.py:104-120
+ *
+ *   for every row of row_len scores keep exactly k = (int64)((double)row_len*ratio)
+ *   entries: all values greater than the k-th largest, plus the lowest-index
+ *   entries equal to it until k are kept (torch.topk's tie order is unspecified;
+ *   on tie-free rows the result is identical).
+ * ------------------------------------------------------------------------- */
+int kvz_select_topk_rows(const void* scores, int64_t rows, int64_t row_len, int64_t k,
+                         int dtype, uint8_t* valid_out, int32_t* row_counts,
+                         kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * a8+a9  compaction plan + gather    reference: attention/kvcache.py:140-185
+ *
+ * Plan (all layers at once).  For row r = layer*Hkv + h:
+ *   full mask   = ones(sink) ++ valid[r, 0:N] ++ ones(klen - sink - N)
+ *   len_k[r]    = popcount(full mask)
+ *   seg_start[layer, h] = sum_{h'<h} (len_k[layer,h'] + slack)      (slack = 0 -> packed,
+ *                          identical to the reference's cu_len_k[:-1])
+ *   cu_len_k[layer, 0:Hkv+1] = [0, cumsum(len_k[layer])]            (reference layout)
+ *   max_len_k[layer]   = max_h len_k[layer,h]
+ *   tile_base[r, t]    = number of kept tokens of row r before token tile t (tile = KVZ_COMPACT_TILE)
+ * ------------------------------------------------------------------------- */
+#define KVZ_COMPACT_TILE 1024
+size_t kvz_compact_plan_bytes(int layers, int Hkv, int klen); /* bytes for tile_base */
+int kvz_compact_plan(const uint8_t* valid, int layers, int Hkv, int N, int sink, int klen,
+                     int slack,
+                     int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
+                     int32_t* tile_base, kvz_stream_t stream);
+
+/* Gather for one layer: order-preserving, head-major.
+ *   k_out[seg_start[h] + j, :] = k[h, src_j, :]   for the j-th kept token of head h (same for v)
+ * k, v       : [Hkv, klen, D] rows contiguous, head stride in_head_stride elements
+ * valid      : this layer's [Hkv, N] bytes;  tile_base: this layer's [Hkv, ntiles]
+ * k_out,v_out: [total_rows, D]
+ */
+int kvz_compact_layer(const void* k, const void* v, int64_t in_head_stride,
+                      const uint8_t* valid, const int32_t* tile_base, const int32_t* seg_start,
+                      int Hkv, int N, int sink, int klen, int D, int elem_bytes,
+                      void* k_out, void* v_out, kvz_stream_t stream);
+
+/* Batched gather over all layers in ONE launch.  k_ptrs/v_ptrs/k_out_ptrs/v_out_ptrs are DEVICE
+ * arrays of `layers` pointers; valid/tile_base/seg_start are the full plan arrays. */
+int kvz_compact_layers(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
+                       const uint8_t* valid, const int32_t* tile_base, const int32_t* seg_start,
+                       int layers, int Hkv, int N, int sink, int klen, int D, int elem_bytes,
+                       void* const* k_out_ptrs, void* const* v_out_ptrs, kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * a11  update_flatten_view           reference: csrc/csrc/cuda_api.cu:15-111
+ *
+ * Reference-exact out-of-place rebuild:
+ *   out = cat_h( cache[cu_headlens[h] : cu_headlens[h]+headlens[h]] , state[h*t:(h+1)*t] )
+ * cache [sum, D], state [Hkv*t, D], out [sum_h headlens[h] + Hkv*t, D]
+ * ------------------------------------------------------------------------- */
+int kvz_update_flatten_view(const void* cache, const void* state,
+                            const int32_t* headlens, const int32_t* cu_headlens,
+                            int Hkv, int t, int D, int elem_bytes,
+                            void* out, kvz_stream_t stream);
+
+/* a10 (MI355X layout)  O(t) in-place append into per-head slack:
+ *   cache[seg_start[h] + cur_len[h] + i, :] = state[h, i, :]    i in [0,t)
+ * state rows contiguous, head stride state_head_stride elements. Both K and V in one launch. */
+int kvz_append_inplace(void* k_cache, void* v_cache,
+                       const void* k_state, const void* v_state, int64_t state_head_stride,
+                       const int32_t* seg_start, const int32_t* cur_len,
+                       int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * a13  variable-length attention     reference call site: attention/attn.py:56-73
+ *      (flash_attn_varlen_func, flash-attn 2.7.4.post1, un-vendored third party)
+ *
+ * Every KV head is one ragged "sequence"; its G query heads are MQA heads.
+ *   q   : [Hkv*q_len, G, D]   (row = h*q_len + i)
+ *   k,v : [rows, D]; head h owns rows k_start[h] .. k_start[h]+k_len[h]
+ *   out : [Hkv*q_len, G, D]
+ *   causal (bottom-right aligned): query i sees key j iff j <= i + (k_len[h] - q_len)
+ *   P = softmax(q.k^T * scale) in fp32, out = P.v rounded to half
+ * ------------------------------------------------------------------------- */
+size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k);
+int kvz_varlen_attn(const void* q, const void* k, const void* v,
+                    const int32_t* k_start, const int32_t* k_len,
+                    int Hkv, int G, int q_len, int D, int max_len_k,
+                    float scale, int causal, int dtype,
+                    void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVZIP_HIP_H */

@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI library ``libkvzip_hip.so`` (declared in ``include/kvzip_hip.h``).
+
+The product path has NO CPU fallback: if the HIP library is missing or a kernel reports an error the
+call raises.  (The CPU oracle lives under ``oracle/`` and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvzip_hip.so")
+
+KVZ_F16, KVZ_BF16 = 0, 1
+
+# name -> (restype, argtypes); mirrors include/kvzip_hip.h one to one
+_vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
+SIGNATURES = {
+    "kvz_abi_version": (_i, []),
+    "kvz_last_error": (C.c_char_p, []),
+    "kvz_score_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "kvz_score_chunk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "kvz_select_workspace_bytes": (_sz, []),
+    "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvz_select_topk_rows": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
+    "kvz_compact_plan_bytes": (_sz, [_i, _i, _i]),
+    "kvz_compact_plan": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvz_compact_layer": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "kvz_compact_layers": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class KvzError(RuntimeError):
+    """Raised when a C-ABI entry point returns a non-zero code (mirrors the reference's TORCH_CHECK
+    RuntimeError, csrc/csrc/cuda_api.cu:73-74)."""
+
+
+def load() -> C.CDLL:
+    """Load the library once; fail loudly when it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KvzError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C kvzip_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kvz_abi_version() != 1:
+        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, who: str) -> None:
+    if rc != 0:
+        msg = load().kvz_last_error()
+        raise KvzError(f"{who} failed (code {rc}): {msg.decode() if msg else ''}")

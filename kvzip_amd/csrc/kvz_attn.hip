@@ -1,0 +1,302 @@
+// kvz_attn.hip — variable-length (ragged per KV head) post-prune attention for gfx950.
+//
+// Replaces the reference's call into flash_attn_varlen_func (attention/attn.py:56-73; flash-attn
+// 2.7.4.post1, third party, not vendored): every KV head is one ragged "sequence", its G query heads
+// are MQA heads, causal mask bottom-right aligned.
+//
+// Decode (q_len = 1) is HBM-bound: every kept K and V row is read exactly once per generated token.
+// Design: split-K "flash decoding".
+//   grid = (splits, Hkv, row tiles of 16 query rows); a block owns one key chunk of one head, its 4
+//   waves stride over 32-key tiles of the chunk.
+//   S^T = K.Q^T on v_mfma_f32_16x16x32 with K rows loaded straight from HBM as the A operand (16-byte
+//   contiguous per lane, no LDS); softmax state lives in registers (lane = one query row);
+//   O^T += V^T.P^T with V staged through a per-wave padded LDS tile and read back transposed by
+//   ds_read_b64_tr_b16.  A second small kernel merges the per-split partials.
+#include "kvz_common.h"
+
+namespace kvz {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct HalfTraits;
+template <> struct HalfTraits<_Float16> {
+    typedef h8 v8;
+    __device__ static inline f4 mfma(v8 a, v8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct HalfTraits<__bf16> {
+    typedef b8 v8;
+    __device__ static inline f4 mfma(v8 a, v8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_WAVES = 4;
+constexpr int AT_KT = 32;           // keys per wave-tile
+constexpr int AT_RT = 16;           // query rows per block (MFMA N)
+
+template <int D> struct AttnCfg {
+    static constexpr int ROW_BYTES = D * 2;
+    static constexpr int VSTRIDE = ROW_BYTES + 32;          // padded LDS row: conflict-free tr reads
+    static constexpr int WAVE_LDS = AT_KT * VSTRIDE;        // bytes of V staging per wave
+    static constexpr int KK = D / 32;                       // MFMA k-steps over the head dim
+    static constexpr int DB = D / 16;                       // 16-wide output column blocks
+    static constexpr int CPR = ROW_BYTES / 16;              // 16-byte chunks per row
+    static constexpr int VLOADS = AT_KT * CPR / WAVE;       // 16-byte V loads per lane per tile
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const int32_t* __restrict__ k_start,
+    const int32_t* __restrict__ k_len, int G, int q_len, int chunk, float scale, int causal,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int n_splits, int n_rtiles) {
+    typedef AttnCfg<D> C;
+    typedef typename HalfTraits<T>::v8 v8;
+    const int split = blockIdx.x, h = blockIdx.y, rt = blockIdx.z;
+    const int len = k_len[h];
+    const int c0 = split * chunk;
+    if (c0 >= len) return;
+    const int c1 = min(len, c0 + chunk);
+    const int R = q_len * G;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[AT_WAVES * C::WAVE_LDS];
+    char* wl = lds + wave * C::WAVE_LDS;
+
+    // ---- stationary Q fragment (B operand of S^T = K.Q^T): col = query row, k = head-dim slice ----
+    const int qrow = rt * AT_RT + l15;
+    const bool qvalid = qrow < R;
+    v8 qf[C::KK];
+    {
+        const T* qp = q + ((int64_t)h * R + (qvalid ? qrow : 0)) * D + quad * 8;
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+            u32x4 raw = *reinterpret_cast<const u32x4*>(qp + kk * 32);
+            if (!qvalid) raw = u32x4{0, 0, 0, 0};
+            qf[kk] = __builtin_bit_cast(v8, raw);
+        }
+    }
+    // last visible key index for this lane's query row (bottom-right aligned causal mask)
+    int limit = causal ? (qrow / G) + len - q_len : len - 1;
+    if (!qvalid) limit = -1;
+
+    const char* kbase = reinterpret_cast<const char*>(k) + (int64_t)k_start[h] * C::ROW_BYTES;
+    const char* vbase = reinterpret_cast<const char*>(v) + (int64_t)k_start[h] * C::ROW_BYTES;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f4 o[C::DB];
+#pragma unroll
+    for (int i = 0; i < C::DB; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const float sl2 = scale * 1.44269504088896340736f;  // work in the exp2 domain
+
+    for (int t0 = c0 + wave * AT_KT; t0 < c1; t0 += AT_WAVES * AT_KT) {
+        // ---- issue all HBM loads of this tile: K (MFMA A operands) and V (to be staged) ----------
+        u32x4 kraw[2][C::KK];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            int key = t0 + sub * 16 + l15;
+            key = key < len ? key : len - 1;  // clamp (masked below)
+            const char* kp = kbase + (int64_t)key * C::ROW_BYTES + quad * 16;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) kraw[sub][kk] = *reinterpret_cast<const u32x4*>(kp + kk * 64);
+        }
+        u32x4 vraw[C::VLOADS];
+#pragma unroll
+        for (int it = 0; it < C::VLOADS; ++it) {
+            const int c = it * WAVE + lane;
+            int key = t0 + c / C::CPR;
+            key = key < len ? key : len - 1;
+            vraw[it] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * C::ROW_BYTES + (c % C::CPR) * 16);
+        }
+        // ---- S^T = K.Q^T : rows = keys (quad*4+reg within each 16-key sub tile), col = query row ----
+        f4 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            s[sub] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk)
+                s[sub] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, kraw[sub][kk]), qf[kk], s[sub]);
+        }
+        // ---- stage V into the padded per-wave LDS tile -------------------------------------------
+#pragma unroll
+        for (int it = 0; it < C::VLOADS; ++it) {
+            const int c = it * WAVE + lane;
+            *reinterpret_cast<u32x4*>(wl + (c / C::CPR) * C::VSTRIDE + (c % C::CPR) * 16) = vraw[it];
+        }
+        // ---- online softmax (exp2 domain), one query row per lane ------------------------------------
+        float sv[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = t0 + (j >> 2) * 16 + quad * 4 + (j & 3);
+            float x = s[j >> 2][j & 3] * sl2;
+            x = (key <= limit && key < c1) ? x : -INFINITY;
+            sv[j] = x;
+            tmax = fmaxf(tmax, x);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_safe);
+        float psum = 0.f;
+        v8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = exp2f(sv[j] - m_safe);
+            psum += p;
+            pb[j] = (T)p;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < C::DB; ++i) {
+            o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
+        }
+        // ---- O^T += V^T.P^T : A = V^T (transposed LDS reads), B = P^T (already in registers) ----------
+        // lane t of a 16-lane group supplies the address of 4 consecutive halfs of row (t>>2), cols (t&3)*4..+3
+        // of a 4(key) x 16(d) block; after the hardware transpose lane c holds column c = 4 keys of one d.
+        const char* trp = wl + (quad * 4 + (l15 >> 2)) * C::VSTRIDE + (l15 & 3) * 8;
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+            s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s4*)(trp + db * 32));
+            s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s4*)(trp + 16 * C::VSTRIDE + db * 32));
+            s8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, both), pb, o[db]);
+        }
+    }
+
+    // ---- merge the 4 waves of the block through LDS (each wave writes only its own region) ----------
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    float* wo = reinterpret_cast<float*>(wl);            // [16 q][D]
+    float* wm = wo + AT_RT * D;                          // [16] m, [16] l
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wo[l15 * D + db * 16 + quad * 4 + r] = o[db][r];
+    if (quad == 0) { wm[l15] = m_run; wm[16 + l15] = l_run; }
+    __syncthreads();
+
+    const int64_t pbase = (((int64_t)h * n_rtiles + rt) * n_splits + split) * AT_RT;
+    for (int e = threadIdx.x; e < AT_RT * D; e += AT_THREADS) {
+        const int qq = e / D, d = e % D;
+        float mw[AT_WAVES], M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < AT_WAVES; ++w) {
+            mw[w] = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[AT_RT * D + qq];
+            M = fmaxf(M, mw[w]);
+        }
+        float acc = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < AT_WAVES; ++w) {
+            const float* pw = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS);
+            const float wgt = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - M);
+            acc += wgt * pw[qq * D + d];
+            lsum += wgt * pw[AT_RT * D + 16 + qq];
+        }
+        part_o[(pbase + qq) * D + d] = acc;
+        if (d == 0) {
+            part_ml[(pbase + qq) * 2] = M;
+            part_ml[(pbase + qq) * 2 + 1] = lsum;
+        }
+    }
+}
+
+// merge the per-split partials: one block per (head, row tile)
+template <typename T, int D>
+__global__ __launch_bounds__(AT_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
+                                                                        const float* __restrict__ part_ml,
+                                                                        const int32_t* __restrict__ k_len, int G,
+                                                                        int q_len, int chunk, int n_splits,
+                                                                        int n_rtiles, T* __restrict__ out) {
+    const int h = blockIdx.x, rt = blockIdx.y;
+    const int R = q_len * G;
+    const int len = k_len[h];
+    const int nsp = (len + chunk - 1) / chunk;
+    const int rows = min(AT_RT, R - rt * AT_RT);
+    const int64_t base = ((int64_t)h * n_rtiles + rt) * n_splits * AT_RT;
+    for (int e = threadIdx.x; e < rows * D; e += AT_THREADS) {
+        const int qq = e / D, d = e % D;
+        float M = -INFINITY;
+        for (int s = 0; s < nsp; ++s) M = fmaxf(M, part_ml[(base + (int64_t)s * AT_RT + qq) * 2]);
+        float acc = 0.f, lsum = 0.f;
+        for (int s = 0; s < nsp; ++s) {
+            const int64_t pi = base + (int64_t)s * AT_RT + qq;
+            const float ms = part_ml[pi * 2];
+            const float wgt = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
+            acc += wgt * part_o[pi * D + d];
+            lsum += wgt * part_ml[pi * 2 + 1];
+        }
+        const float r = (lsum > 0.f) ? acc / lsum : 0.f;
+        out[((int64_t)h * R + rt * AT_RT + qq) * D + d] = (T)r;
+    }
+}
+
+static inline int attn_chunk(int Hkv, int max_len_k) {
+    // aim for ~2048 (head, chunk) work items; chunk is a multiple of one block-iteration (128 keys)
+    int64_t c = ((int64_t)Hkv * max_len_k + 2047) / 2048;
+    c = (c + 127) / 128 * 128;
+    if (c < 128) c = 128;
+    return (int)c;
+}
+
+template <typename T, int D>
+static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len, int Hkv,
+                       int G, int q_len, int max_len_k, float scale, int causal, void* out, void* ws,
+                       hipStream_t stream) {
+    const int chunk = attn_chunk(Hkv, max_len_k);
+    const int n_splits = (max_len_k + chunk - 1) / chunk > 0 ? (max_len_k + chunk - 1) / chunk : 1;
+    const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
+    float* part_o = reinterpret_cast<float*>(ws);
+    float* part_ml = part_o + (size_t)Hkv * n_rtiles * n_splits * AT_RT * D;
+    hipLaunchKernelGGL((varlen_attn_split_kernel<T, D>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
+                       reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
+                       k_start, k_len, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
+    KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
+    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles), dim3(AT_THREADS), 0, stream, part_o,
+                       part_ml, k_len, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
+    KVZ_CHECK_LAUNCH("varlen_attn_combine_kernel");
+    return KVZ_OK;
+}
+
+}  // namespace kvz
+
+using namespace kvz;
+
+extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k) {
+    if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0 || max_len_k < 0) return 0;
+    const int chunk = attn_chunk(Hkv, max_len_k);
+    int n_splits = (max_len_k + chunk - 1) / chunk;
+    if (n_splits < 1) n_splits = 1;
+    const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
+    return (size_t)Hkv * n_rtiles * n_splits * AT_RT * (D + 2) * sizeof(float);
+}
+
+extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, const int32_t* k_start,
+                               const int32_t* k_len, int Hkv, int G, int q_len, int D, int max_len_k, float scale,
+                               int causal, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(q && k && v && k_start && k_len && out && ws, KVZ_EINVAL, "kvz_varlen_attn: null pointer");
+    KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0 && max_len_k >= 0, KVZ_EINVAL, "kvz_varlen_attn: bad shape");
+    KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_varlen_attn: head_dim %d unsupported (64 or 128)", D);
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_varlen_attn: bad dtype %d", dtype);
+    KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), KVZ_EINVAL, "kvz_varlen_attn: q/k/v must be 16-byte aligned");
+    KVZ_REQUIRE((q_len * G + AT_RT - 1) / AT_RT <= 65535, KVZ_EINVAL, "kvz_varlen_attn: too many query rows");
+    KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
+                "kvz_varlen_attn: workspace too small");
+    if (dtype == KVZ_F16) {
+        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+    }
+    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+}

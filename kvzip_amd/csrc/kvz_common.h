@@ -1,0 +1,78 @@
+// kvz_common.h — shared device/host helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/kvzip_hip.h"
+
+namespace kvz {
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define KVZ_REQUIRE(cond, code, ...)          \
+    do {                                      \
+        if (!(cond)) {                        \
+            kvz::set_error(__VA_ARGS__);      \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+#define KVZ_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            kvz::set_error("%s: launch failed: %s", (name), hipGetErrorString(e_));   \
+            return KVZ_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- half / bf16 bit helpers ------------------------------------------------------------
+// Monotone map from the 16-bit pattern of an fp16 / bf16 value to an unsigned key such that
+// a > b (as floats)  <=>  key(a) > key(b).  (-0 maps just below +0; both compare equal to 0 as floats,
+// see select kernels for why that is harmless.)
+__host__ __device__ static inline uint32_t order_key16(uint32_t bits) {
+    return (bits & 0x8000u) ? (~bits & 0xFFFFu) : (bits | 0x8000u);
+}
+__host__ __device__ static inline uint32_t order_key16_inv(uint32_t key) {
+    return (key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu);
+}
+
+__device__ static inline float half_bits_to_float(uint32_t bits, int dtype) {
+    if (dtype == KVZ_BF16) return __uint_as_float(bits << 16);
+    _Float16 h;
+    unsigned short s = (unsigned short)bits;
+    __builtin_memcpy(&h, &s, 2);
+    return (float)h;
+}
+
+// ---- wave primitives ----------------------------------------------------------------------
+__device__ static inline int lane_id() { return threadIdx.x & 63; }
+
+__device__ static inline int wave_reduce_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ static inline int wave_inclusive_scan(int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(v, o, 64);
+        if (lane_id() >= o) v += n;
+    }
+    return v;
+}
+
+}  // namespace kvz

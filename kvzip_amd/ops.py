@@ -1,0 +1,276 @@
+"""Tensor-level wrappers over the C ABI: torch is used for device memory and streams only.
+
+Every function takes CUDA(=HIP) tensors, passes raw ``data_ptr()`` values plus the current HIP stream to
+``libkvzip_hip.so`` and returns torch tensors that it allocated.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import KVZ_BF16, KVZ_F16, KvzError, check
+
+COMPACT_TILE = 1024
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float16:
+        return KVZ_F16
+    if dtype == torch.bfloat16:
+        return KVZ_BF16
+    raise KvzError(f"unsupported dtype {dtype}: the path computes in fp16 or bf16 "
+                   "(reference csrc/csrc/static_switch.h:3-12)")
+
+
+def _stream(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise KvzError("the HIP path needs device tensors (no CPU fallback)")
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------------
+# a1  scoring
+# --------------------------------------------------------------------------------------------------
+def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int, start: int, end: int,
+                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """KV importance score of one layer / one chunk (reference attention/score.py:36-65).
+
+    query_states ``[1, H, q, D]``, key_states ``[1, Hkv, klen, D]`` (rows contiguous; the head stride may be
+    larger than ``klen*D`` — views into a cache with slack are fine).  Returns ``[1, Hkv, end-start]``.
+    """
+    lib = _lib.load()
+    bsz, H, q_len, D = query_states.shape
+    _, Hkv, klen, _ = key_states.shape
+    assert bsz == 1, "batch size is 1 on this path (reference attention/score.py:29)"
+    assert H % Hkv == 0
+    G = H // Hkv
+    m = end - start
+    assert m > 0 and sink >= 0 and start >= sink and end <= klen - q_len, (sink, start, end, klen, q_len)
+    dt = _dtype_code(query_states.dtype)
+    assert key_states.dtype == query_states.dtype
+    assert query_states.stride(-1) == 1 and query_states.stride(-2) == D
+    assert key_states.stride(-1) == 1 and key_states.stride(-2) == D
+    if out is None:
+        out = torch.empty((1, Hkv, m), dtype=query_states.dtype, device=query_states.device)
+    assert out.stride(-1) == 1 and out.shape[-1] == m
+    need = lib.kvz_score_workspace_bytes(Hkv, G, q_len, m)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=query_states.device)
+    rc = lib.kvz_score_chunk(query_states.data_ptr(), query_states.stride(1), key_states.data_ptr(),
+                             key_states.stride(1), klen, sink, start, end, q_len, Hkv, G, D, dt,
+                             out.data_ptr(), out.stride(1), workspace.data_ptr(), workspace.numel(),
+                             _stream(query_states))
+    check(rc, "kvz_score_chunk")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# a4 / a5  selection
+# --------------------------------------------------------------------------------------------------
+def select_threshold(score: torch.Tensor, ratio: float, row_len: Optional[int] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Global-threshold selection (reference attention/score.py:88-102) — device side only.
+
+    Returns ``(valid bool like score, thres f32[1] (device), kept i64[1] (device), row_counts i32[rows] or None)``.
+    No host synchronisation happens here.
+    """
+    lib = _lib.load()
+    score = score.contiguous()
+    n = score.numel()
+    dt = _dtype_code(score.dtype)
+    dev = score.device
+    valid = torch.empty(score.shape, dtype=torch.bool, device=dev)
+    thres = torch.empty(1, dtype=torch.float32, device=dev)
+    kept = torch.empty(1, dtype=torch.int64, device=dev)
+    rows = None
+    if row_len is not None:
+        rows = torch.empty(n // row_len, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.kvz_select_workspace_bytes(), dtype=torch.uint8, device=dev)
+    rc = lib.kvz_select_threshold(score.data_ptr(), n, float(ratio), dt, valid.data_ptr(),
+                                  row_len if row_len is not None else n, _ptr(rows), thres.data_ptr(),
+                                  kept.data_ptr(), ws.data_ptr(), ws.numel(), _stream(score))
+    check(rc, "kvz_select_threshold")
+    return valid, thres, kept, rows
+
+
+def select_topk_rows(score: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-row exact top-k over the last dim (reference attention/score.py:104-120)."""
+    lib = _lib.load()
+    score = score.contiguous()
+    row_len = score.shape[-1]
+    rows = score.numel() // row_len
+    valid = torch.empty(score.shape, dtype=torch.bool, device=score.device)
+    counts = torch.empty(rows, dtype=torch.int32, device=score.device)
+    rc = lib.kvz_select_topk_rows(score.data_ptr(), rows, row_len, int(k), _dtype_code(score.dtype),
+                                  valid.data_ptr(), counts.data_ptr(), _stream(score))
+    check(rc, "kvz_select_topk_rows")
+    return valid, counts
+
+
+# --------------------------------------------------------------------------------------------------
+# a8 / a9  compaction
+# --------------------------------------------------------------------------------------------------
+class CompactPlan:
+    """Device-side result of ``kvz_compact_plan`` for all layers (reference attention/kvcache.py:168-185)."""
+
+    def __init__(self, layers: int, Hkv: int, N: int, sink: int, klen: int, slack: int, device):
+        self.layers, self.Hkv, self.N, self.sink, self.klen, self.slack = layers, Hkv, N, sink, klen, slack
+        self.ntiles = (klen + COMPACT_TILE - 1) // COMPACT_TILE
+        i32 = dict(dtype=torch.int32, device=device)
+        # one allocation so that a single D2H copy brings all the metadata to the host
+        meta = torch.empty(layers * Hkv * 2 + layers * (Hkv + 1) + layers, **i32)
+        o = 0
+        self.len_k = meta[o:o + layers * Hkv].view(layers, Hkv); o += layers * Hkv
+        self.seg_start = meta[o:o + layers * Hkv].view(layers, Hkv); o += layers * Hkv
+        self.cu_len_k = meta[o:o + layers * (Hkv + 1)].view(layers, Hkv + 1); o += layers * (Hkv + 1)
+        self.max_len_k = meta[o:o + layers]
+        self.meta = meta
+        self.tile_base = torch.empty(layers * Hkv * self.ntiles, **i32)
+
+
+def compact_plan(valid: torch.Tensor, sink: int, klen: int, slack: int = 0) -> CompactPlan:
+    """valid ``[L, 1, Hkv, N]`` (or ``[L, Hkv, N]``) bool -> per-layer varlen metadata on the device."""
+    lib = _lib.load()
+    valid = valid.contiguous()
+    L = valid.shape[0]
+    Hkv, N = valid.shape[-2], valid.shape[-1]
+    plan = CompactPlan(L, Hkv, N, sink, klen, slack, valid.device)
+    rc = lib.kvz_compact_plan(valid.data_ptr(), L, Hkv, N, sink, klen, slack, plan.len_k.data_ptr(),
+                              plan.cu_len_k.data_ptr(), plan.seg_start.data_ptr(), plan.max_len_k.data_ptr(),
+                              plan.tile_base.data_ptr(), _stream(valid))
+    check(rc, "kvz_compact_plan")
+    plan.valid = valid
+    return plan
+
+
+def compact_layer(k: torch.Tensor, v: torch.Tensor, plan: CompactPlan, layer: int, total_rows: int
+                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Gather one layer: k, v ``[1, Hkv, klen, D]`` -> ``[total_rows, D]`` each (order preserving, head major)."""
+    lib = _lib.load()
+    _, Hkv, klen, D = k.shape
+    assert klen == plan.klen and Hkv == plan.Hkv
+    assert k.stride(-1) == 1 and k.stride(-2) == D and v.stride() == k.stride()
+    k_out = torch.empty((total_rows, D), dtype=k.dtype, device=k.device)
+    v_out = torch.empty((total_rows, D), dtype=v.dtype, device=v.device)
+    valid_l = plan.valid.view(plan.layers, Hkv, plan.N)[layer]
+    tb = plan.tile_base.view(plan.layers, Hkv * plan.ntiles)[layer]
+    rc = lib.kvz_compact_layer(k.data_ptr(), v.data_ptr(), k.stride(1), valid_l.data_ptr(), tb.data_ptr(),
+                               plan.seg_start[layer].data_ptr(), Hkv, plan.N, plan.sink, klen, D,
+                               k.element_size(), k_out.data_ptr(), v_out.data_ptr(), _stream(k))
+    check(rc, "kvz_compact_layer")
+    return k_out, v_out
+
+
+def compact_layers(ks: Sequence[torch.Tensor], vs: Sequence[torch.Tensor], plan: CompactPlan,
+                   totals: Sequence[int]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """All layers in ONE launch (pointer tables).  ``totals[l]`` = rows to allocate for layer l."""
+    lib = _lib.load()
+    L = len(ks)
+    assert L == plan.layers
+    _, Hkv, klen, D = ks[0].shape
+    dev = ks[0].device
+    hs = ks[0].stride(1)
+    for k, v in zip(ks, vs):
+        assert k.shape == ks[0].shape and v.shape == ks[0].shape
+        assert k.stride(-1) == 1 and k.stride(-2) == D and k.stride(1) == hs and v.stride() == k.stride()
+    k_outs = [torch.empty((int(t), D), dtype=ks[0].dtype, device=dev) for t in totals]
+    v_outs = [torch.empty((int(t), D), dtype=ks[0].dtype, device=dev) for t in totals]
+    table = torch.tensor([[t.data_ptr() for t in ks], [t.data_ptr() for t in vs],
+                          [t.data_ptr() for t in k_outs], [t.data_ptr() for t in v_outs]],
+                         dtype=torch.int64).to(dev, non_blocking=False)
+    rc = lib.kvz_compact_layers(table[0].data_ptr(), table[1].data_ptr(), hs, plan.valid.data_ptr(),
+                                plan.tile_base.data_ptr(), plan.seg_start.data_ptr(), L, Hkv, plan.N, plan.sink,
+                                klen, D, ks[0].element_size(), table[2].data_ptr(), table[3].data_ptr(),
+                                _stream(ks[0]))
+    check(rc, "kvz_compact_layers")
+    # keep the pointer table alive until the kernel has consumed it
+    table.record_stream(torch.cuda.current_stream(dev))
+    return k_outs, v_outs
+
+
+# --------------------------------------------------------------------------------------------------
+# a10 / a11  append
+# --------------------------------------------------------------------------------------------------
+def update_flatten_view(cache: torch.Tensor, state: torch.Tensor, headlens: torch.Tensor,
+                        cu_headlens: torch.Tensor) -> torch.Tensor:
+    """Drop-in for ``tiny_api_cuda.update_flatten_view`` (reference csrc/csrc/cuda_api.cu:68-111):
+    same arguments, same dtype checks (-> RuntimeError), returns a fresh tensor."""
+    lib = _lib.load()
+    if headlens.dtype != torch.int32:
+        raise KvzError("expected headlens to be int32")
+    if cu_headlens.dtype != torch.int32:
+        raise KvzError("expected cu_headlens to be int32")
+    origin_len, dim = cache.shape
+    head_num = headlens.shape[0]
+    if state.shape[0] % head_num != 0:
+        raise KvzError("state rows must be divisible by head count")
+    t = state.shape[0] // head_num
+    cache = cache.contiguous()
+    state = state.contiguous()
+    out = torch.empty((origin_len + head_num * t, dim), dtype=cache.dtype, device=cache.device)
+    rc = lib.kvz_update_flatten_view(cache.data_ptr(), state.data_ptr(), headlens.data_ptr(),
+                                     cu_headlens.data_ptr(), head_num, t, dim, cache.element_size(),
+                                     out.data_ptr(), _stream(cache))
+    check(rc, "kvz_update_flatten_view")
+    return out
+
+
+def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.Tensor, v_state: torch.Tensor,
+                   seg_start: torch.Tensor, cur_len: torch.Tensor) -> None:
+    """O(t) append of ``k_state/v_state [1, Hkv, t, D]`` after each head's current rows (slack layout)."""
+    lib = _lib.load()
+    _, Hkv, t, D = k_state.shape
+    assert k_state.stride(-1) == 1 and k_state.stride(-2) == D and v_state.stride() == k_state.stride()
+    rc = lib.kvz_append_inplace(k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(), v_state.data_ptr(),
+                                k_state.stride(1), seg_start.data_ptr(), cur_len.data_ptr(), Hkv, t, D,
+                                k_cache.element_size(), _stream(k_cache))
+    check(rc, "kvz_append_inplace")
+
+
+# --------------------------------------------------------------------------------------------------
+# a13  variable-length attention
+# --------------------------------------------------------------------------------------------------
+def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor,
+                q_len: int, max_len_k: int, causal: bool = True, softmax_scale: Optional[float] = None,
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q ``[Hkv*q_len, G, D]``; k, v ``[rows, D]`` (or ``[rows, 1, D]``); head h owns rows
+    ``k_start[h] : k_start[h]+k_len[h]``.  Returns ``[Hkv*q_len, G, D]``."""
+    lib = _lib.load()
+    HQ, G, D = q.shape
+    Hkv = HQ // q_len
+    assert Hkv * q_len == HQ and k_start.shape[0] == Hkv and k_len.shape[0] == Hkv
+    assert k_start.dtype == torch.int32 and k_len.dtype == torch.int32
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    out = torch.empty_like(q)
+    need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, int(max_len_k))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(), Hkv, G,
+                             q_len, D, int(max_len_k), float(scale), 1 if causal else 0, _dtype_code(q.dtype),
+                             out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
+    check(rc, "kvz_varlen_attn")
+    return out
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                           softmax_scale=None, causal=False, seqused_k=None):
+    """Call-compatible stand-in for the reference's use of ``flash_attn.flash_attn_varlen_func``
+    (reference attention/attn.py:61-71): every "sequence" is one KV head with ``nheads_k = 1``."""
+    assert dropout_p == 0.0
+    Hkv = cu_seqlens_k.shape[0] - 1
+    q_len = int(max_seqlen_q)
+    k2 = k.view(-1, k.shape[-1])
+    v2 = v.view(-1, v.shape[-1])
+    k_start = cu_seqlens_k[:-1].contiguous()
+    k_len = (cu_seqlens_k[1:] - cu_seqlens_k[:-1]).contiguous() if seqused_k is None else seqused_k
+    assert q.shape[0] == Hkv * q_len
+    return varlen_attn(q, k2, v2, k_start, k_len, q_len, int(max_seqlen_k), causal=causal,
+                       softmax_scale=softmax_scale)

@@ -1,0 +1,307 @@
+"""Generate golden vectors by IMPORTING the reference's own Python (runs only in the build container,
+where /root/reference exists; nothing from the reference is copied — only inputs/outputs are stored).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Shims: ``tiny_api_cuda.update_flatten_view`` (the reference's only native op, CUDA-only) is
+replaced by the CPU restatement of csrc/csrc/cuda_api.cu:29-39 from ``oracle/kvzip_oracle.py``;
+``transformers.HybridCache`` (removed in transformers 5.x, used only by the out-of-scope Gemma3 cache) is a
+dummy class; ``key_cache/value_cache/_seen_tokens`` (created by transformers 4.51.3's DynamicCache.__init__)
+are seeded by hand.
+
+Half tensors are stored as uint16 bit patterns (numpy has no bfloat16).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import kvzip_oracle as orc  # noqa: E402
+
+
+def install_shims():
+    mod = types.ModuleType("tiny_api_cuda")
+    mod.update_flatten_view = orc.update_flatten_view
+    sys.modules["tiny_api_cuda"] = mod
+    import transformers
+    if not hasattr(transformers, "HybridCache"):
+        class HybridCache:  # noqa: D401 - dummy, only subclassed by the out-of-scope RetainHybridCache
+            pass
+        transformers.HybridCache = HybridCache
+    sys.path.insert(0, REF)
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+class StubModel(torch.nn.Module):
+    def __init__(self, L, H, Hkv, dtype):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1, dtype=dtype))
+        self.config = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+
+
+def make_cache(cls, L, H, Hkv, dtype, evict_range):
+    kv = cls(StubModel(L, H, Hkv, dtype), evict_range)
+    kv.key_cache, kv.value_cache, kv._seen_tokens = [], [], 0
+    return kv
+
+
+def gen_score(KVScore):
+    """G1: (Q, K, sink, start, end) -> score, straight from KVScore._get_score."""
+    cases = [
+        # name, dtype, Hkv, G, D, sink, ctx N, start, end, q_len
+        ("f16_d128_g7_first", torch.float16, 2, 7, 128, 30, 100, 30, 70, 53),
+        ("f16_d128_g7_later", torch.float16, 2, 7, 128, 30, 100, 70, 130, 66),
+        ("bf16_d128_g7_first", torch.bfloat16, 2, 7, 128, 30, 100, 30, 70, 53),
+        ("bf16_d128_g4_later", torch.bfloat16, 2, 4, 128, 17, 150, 87, 167, 96),
+        ("f16_d64_g7", torch.float16, 2, 7, 64, 30, 140, 30, 170, 153),
+        ("bf16_d64_g7_later", torch.bfloat16, 2, 7, 64, 8, 140, 70, 148, 91),
+        ("f16_d128_g5", torch.float16, 3, 5, 128, 5, 60, 5, 65, 73),
+        ("f16_d128_g1_tiny", torch.float16, 1, 1, 128, 0, 40, 0, 33, 37),
+    ]
+    out = {}
+    for i, (name, dt, Hkv, G, D, sink, N, start, end, q_len) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + i)
+        klen = sink + N + q_len
+        q = torch.randn(1, Hkv * G, q_len, D, generator=g).to(dt)
+        k = torch.randn(1, Hkv, klen, D, generator=g).to(dt)
+        sc = KVScore()
+        sc.n_heads_kv, sc.dtype, sc.device, sc.n_layers = Hkv, dt, "cpu", 1
+        sc.sink, sc.start_idx, sc.end_idx = sink, start, end
+        sc.init_score()
+        sc._get_score(q, k, 0)
+        out[name + "/q"] = bits(q)
+        out[name + "/k"] = bits(k)
+        out[name + "/score"] = bits(sc.score[0])
+        out[name + "/meta"] = np.array([Hkv, G, D, sink, start, end, q_len, klen, int(dt == torch.bfloat16)], dtype=np.int64)
+    np.savez(os.path.join(OUT, "g1_score.npz"), **out)
+    print("g1_score", len(cases), "cases")
+
+
+RATIOS = [0.0, 1e-9, 0.1, 0.3, 0.6, 0.999999, 1.0, 1.5]
+
+
+def gen_threshold(KVScore):
+    """G2: _threshold with heavy ties (bf16) and with many distinct values (fp16); G3: _threshold_uniform (tie-free)."""
+    sc = KVScore()
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    L, Hkv, N = 3, 4, 512
+    # softmax-max-like scores in (0,1]
+    base = torch.rand(L, 1, Hkv, N, generator=g) ** 4
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        score = base.to(dt)
+        out[f"{tag}/score"] = bits(score)
+        for r in RATIOS:
+            valid, thres = sc._threshold(score, r)
+            out[f"{tag}/valid/{r!r}"] = np.packbits(valid.numpy().reshape(-1))
+            out[f"{tag}/thres/{r!r}"] = np.array([thres], dtype=np.float64)
+        # list-of-layers form (what prune() passes after scoring)
+        lst = [score[i] for i in range(L)]
+        valid, thres = sc._threshold(lst, 0.3)
+        assert torch.equal(valid, sc._threshold(score, 0.3)[0])
+    # odd sizes: n not a multiple of 8, negative / zero scores, N not a multiple of 8
+    odd = torch.randn(2, 1, 3, 157, generator=g).to(torch.float16)
+    odd[0, 0, 0, :5] = 0.0
+    odd[1, 0, 2, 3:9] = -0.0
+    out["odd/score"] = bits(odd)
+    for r in (0.0, 0.25, 0.5, 0.9):
+        valid, thres = sc._threshold(odd, r)
+        out[f"odd/valid/{r!r}"] = np.packbits(valid.numpy().reshape(-1))
+        out[f"odd/thres/{r!r}"] = np.array([thres], dtype=np.float64)
+    np.savez(os.path.join(OUT, "g2_threshold.npz"), **out)
+
+    # G3: tie-free rows (distinct fp16 values per row)
+    out = {}
+    L, Hkv, N = 2, 3, 400
+    vals = torch.arange(1, 20001, dtype=torch.float32) / 20001.0
+    vals = torch.unique(vals.to(torch.float16))
+    rows = []
+    for i in range(L * Hkv):
+        perm = torch.randperm(vals.numel(), generator=g)[:N]
+        rows.append(vals[perm])
+    score = torch.stack(rows).view(L, 1, Hkv, N)
+    out["score"] = bits(score)
+    for r in (0.0, 0.1, 0.3, 0.6, 0.9975, 1.0):
+        valid, thres = sc._threshold_uniform([score[i] for i in range(L)], r)
+        assert thres == 0
+        out[f"valid/{r!r}"] = np.packbits(valid.numpy().reshape(-1))
+    np.savez(os.path.join(OUT, "g3_threshold_uniform.npz"), **out)
+    print("g2/g3 threshold ok")
+
+
+def gen_head_scores(KVScore):
+    """G4: the reference's own known-answer data (utils/head_score/*.pt) and the head-level selection it implies
+    (model/wrapper.py:40-58 + attention/score.py:88-102), independent of the context length."""
+    sc = KVScore()
+    out = {}
+    groups = {"qwen2.5-7b": 0.6, "qwen2.5-14b": 0.6, "llama3.1-8b": 0.6}
+    for name, _ in groups.items():
+        paths = sorted(glob.glob(os.path.join(REF, "utils", "head_score", f"{name}-*.pt")))
+        attn = torch.stack([torch.load(p, map_location="cpu").squeeze() for p in paths], 0).amax(0)  # layer x head
+        out[f"{name}/head_score"] = bits(attn)
+        out[f"{name}/is_bf16"] = np.array([int(attn.dtype == torch.bfloat16)])
+        for ctx_len in (64, 1000):
+            score = attn.unsqueeze(-1).expand(-1, -1, ctx_len).unsqueeze(1)  # [L,1,Hkv,N]
+            for r in (0.3, 0.6, 0.9):
+                valid, thres = sc._threshold(score, r)
+                kept_heads = valid[..., 0].squeeze(1)  # [L, Hkv]
+                assert torch.equal(valid, kept_heads.unsqueeze(1).unsqueeze(-1).expand_as(valid))
+                out[f"{name}/kept/{ctx_len}/{r!r}"] = kept_heads.numpy()
+                out[f"{name}/thres/{ctx_len}/{r!r}"] = np.array([thres], dtype=np.float64)
+    np.savez(os.path.join(OUT, "g4_head_score.npz"), **out)
+    print("g4 head scores ok")
+
+
+def gen_cache_sequence(EvictCache, RetainCache):
+    """G5 + G6: a whole EvictCache life cycle on CPU:
+    prefill update -> init_score -> 2 scoring chunks (update/_get_score/slice) -> prune -> query prefill (t=7)
+    -> 2 decode steps (t=1) -> slice.  RetainCache is run beside it (reference's own cross-oracle)."""
+    for tag, dt, level in (("f16_pair", torch.float16, "pair"), ("bf16_pair", torch.bfloat16, "pair"),
+                           ("f16_uniform", torch.float16, "pair-uniform")):
+        L, H, Hkv, D = 2, 8, 2, 64
+        G = H // Hkv
+        sink, N = 6, 80
+        g = torch.Generator().manual_seed(len(tag))
+        ev = make_cache(EvictCache, L, H, Hkv, dt, (sink, sink + N))
+        rt = make_cache(RetainCache, L, H, Hkv, dt, (sink, sink + N))
+        out = {"meta": np.array([L, H, Hkv, D, sink, N, int(dt == torch.bfloat16)], dtype=np.int64)}
+        K0 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dt) for _ in range(L)]
+        V0 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dt) for _ in range(L)]
+        for l in range(L):
+            ev.update(K0[l].clone(), V0[l].clone(), l)
+            rt.update(K0[l].clone(), V0[l].clone(), l)
+            out[f"K0/{l}"], out[f"V0/{l}"] = bits(K0[l]), bits(V0[l])
+        # scoring: two chunks of 50 / 30 tokens, repeat prompts of q = m + 9 / m + 13 tokens
+        chunks = [(sink, sink + 50, 59), (sink + 50, sink + 80, 43)]
+        for kv in (ev, rt):
+            kv.init_score()
+        for ci, (st, en, q_len) in enumerate(chunks):
+            for kv in (ev, rt):
+                kv.start_idx, kv.end_idx = st, en
+            seen = ev._seen_tokens
+            for l in range(L):
+                q = torch.randn(1, H, q_len, D, generator=g).to(dt)
+                kr = torch.randn(1, Hkv, q_len, D, generator=g).to(dt)
+                vr = torch.randn(1, Hkv, q_len, D, generator=g).to(dt)
+                out[f"sc/{ci}/{l}/q"], out[f"sc/{ci}/{l}/k"], out[f"sc/{ci}/{l}/v"] = bits(q), bits(kr), bits(vr)
+                for kv in (ev, rt):
+                    kfull, _ = kv.update(kr.clone(), vr.clone(), l)
+                    kv._get_score(q, kfull, l)
+            for kv in (ev, rt):
+                kv.slice(seen)
+        for kv in (ev, rt):
+            kv.start_idx, kv.get_score = sink, False
+        for l in range(L):
+            assert torch.equal(ev.score[l], rt.score[l])
+            out[f"score/{l}"] = bits(ev.score[l])
+        ratio = 0.4
+        import io
+        from contextlib import redirect_stdout
+        with redirect_stdout(io.StringIO()):
+            thres, r_ = ev.prune(ratio, level)
+            thres2, r2 = rt.prune(ratio, level)
+        assert thres == thres2 and r_ == r2 and torch.equal(ev.valid, rt.valid)
+        out["ratio"] = np.array([ratio]); out["thres"] = np.array([thres], dtype=np.float64)
+        out["r_real"] = np.array([r_], dtype=np.float64)
+        out["valid"] = ev.valid.numpy()
+        for l in range(L):
+            out[f"flatK/{l}"], out[f"flatV/{l}"] = bits(ev.key_cache[l]), bits(ev.value_cache[l])
+            out[f"len_k/{l}"] = ev.info["len_k"][l].numpy()
+            out[f"cu_len_k/{l}"] = ev.info["cu_len_k"][l].numpy().copy()
+            out[f"max_len_k/{l}"] = np.array([int(ev.info["max_len_k"][l])])
+        # generation: query prefill of 7 tokens, then two decode steps
+        seen = ev._seen_tokens
+        for si, t in enumerate((7, 1, 1)):
+            for l in range(L):
+                q = torch.randn(1, H, t, D, generator=g).to(dt)
+                kn = torch.randn(1, Hkv, t, D, generator=g).to(dt)
+                vn = torch.randn(1, Hkv, t, D, generator=g).to(dt)
+                out[f"gen/{si}/{l}/q"], out[f"gen/{si}/{l}/k"], out[f"gen/{si}/{l}/v"] = bits(q), bits(kn), bits(vn)
+                ke, ve = ev.update(kn.clone(), vn.clone(), l)
+                qe, ke2, ve2, ie = ev.prepare(q, ke, ve, l)
+                kr_, vr_ = rt.update(kn.clone(), vn.clone(), l)
+                qr, kr2, vr2, ir = rt.prepare(q, kr_, vr_, l)
+                # the reference's own cross-check: Evict (compact + append) == Retain (mask gather)
+                assert torch.equal(qe, qr) and torch.equal(ke2, kr2) and torch.equal(ve2, vr2)
+                assert torch.equal(ie["cu_len_k"], ir["cu_len_k"]) and int(ie["max_len_k"]) == int(ir["max_len_k"])
+                out[f"gen/{si}/{l}/q_out"] = bits(qe)
+                out[f"gen/{si}/{l}/k_out"] = bits(ke2.view(-1, D))
+                out[f"gen/{si}/{l}/v_out"] = bits(ve2.view(-1, D))
+                out[f"gen/{si}/{l}/cu_len_q"] = ie["cu_len_q"].numpy().copy()
+                out[f"gen/{si}/{l}/cu_len_k"] = ie["cu_len_k"].numpy().copy()
+                out[f"gen/{si}/{l}/max_len"] = np.array([int(ie["max_len_q"]), int(ie["max_len_k"])])
+                # attention output of the CPU restatement on exactly these tensors (a13, unpinned)
+                cu = ie["cu_len_k"]
+                att = orc.varlen_attn(qe, ke2.view(-1, D), ve2.view(-1, D), cu[:-1].tolist(),
+                                      (cu[1:] - cu[:-1]).tolist(), t, causal=True)
+                out[f"gen/{si}/{l}/attn"] = bits(att)
+        out["seen_after_gen"] = np.array([ev._seen_tokens, ev.get_seq_length()])
+        ev.slice(seen)
+        for l in range(L):
+            out[f"sliced/K/{l}"] = bits(ev.key_cache[l])
+            out[f"sliced/cu_len_k/{l}"] = ev.info["cu_len_k"][l].numpy().copy()
+        out["seen_after_slice"] = np.array([ev._seen_tokens])
+        out["mem_gb"] = np.array([ev._mem()])
+        np.savez(os.path.join(OUT, f"g6_cache_{tag}.npz"), **out)
+        print("g6", tag, "thres", thres, "r_real", r_)
+
+
+def gen_attn():
+    """G7: varlen attention vectors from the oracle restatement (a13; parity unpinned, see module header)."""
+    out = {}
+    cases = [("f16_decode", torch.float16, 4, 7, 128, 1, [37, 1, 260, 129]),
+             ("bf16_decode", torch.bfloat16, 2, 4, 128, 1, [300, 33]),
+             ("f16_prefill", torch.float16, 2, 7, 128, 9, [64, 140]),
+             ("f16_d64", torch.float16, 2, 7, 64, 3, [50, 131]),
+             ("f16_short", torch.float16, 2, 5, 128, 4, [2, 9])]
+    for i, (name, dt, Hkv, G, D, q_len, lens) in enumerate(cases):
+        g = torch.Generator().manual_seed(900 + i)
+        slack = 5
+        starts, tot = [], 0
+        for ln in lens:
+            starts.append(tot)
+            tot += ln + slack
+        q = torch.randn(Hkv * q_len, G, D, generator=g).to(dt)
+        k = torch.randn(tot, D, generator=g).to(dt)
+        v = torch.randn(tot, D, generator=g).to(dt)
+        o = orc.varlen_attn(q, k, v, starts, lens, q_len, causal=True)
+        out[f"{name}/q"], out[f"{name}/k"], out[f"{name}/v"], out[f"{name}/out"] = bits(q), bits(k), bits(v), bits(o)
+        out[f"{name}/k_start"] = np.array(starts, dtype=np.int32)
+        out[f"{name}/k_len"] = np.array(lens, dtype=np.int32)
+        out[f"{name}/meta"] = np.array([Hkv, G, D, q_len, int(dt == torch.bfloat16)], dtype=np.int64)
+    np.savez(os.path.join(OUT, "g7_attn.npz"), **out)
+    print("g7 attn ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    install_shims()
+    from attention.score import KVScore
+    from attention.kvcache import EvictCache, RetainCache
+    gen_score(KVScore)
+    gen_threshold(KVScore)
+    gen_head_scores(KVScore)
+    gen_cache_sequence(EvictCache, RetainCache)
+    gen_attn()
+    total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
+    print(f"wrote {OUT}: {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,384 @@
+"""GPU parity tests proper: every HIP kernel, called through the C ABI, against the golden vectors and the
+CPU oracle on seeded inputs.  Integer / byte work (selection masks, compaction, append, metadata) must be
+BIT-EXACT; floating point work carries the tolerance stated in the test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import kvzip_oracle as orc
+from conftest import from_bits, load_golden, to_bits, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def ops():
+    from kvzip_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# a4 selection
+# ------------------------------------------------------------------------------------------------
+def _select(score_cpu, ratio, row_len=None):
+    valid, thres, kept, rows = ops().select_threshold(score_cpu.to(DEV), ratio, row_len=row_len)
+    torch.cuda.synchronize()
+    return valid.cpu(), float(thres.item()), int(kept.item()), (rows.cpu() if rows is not None else None)
+
+
+def test_select_threshold_golden():
+    g = load_golden("g2_threshold.npz")
+    for tag, bf in (("bf16", True), ("f16", False), ("odd", False)):
+        score = from_bits(g[f"{tag}/score"], bf)
+        for key in [k for k in g.files if k.startswith(f"{tag}/thres/")]:
+            r = key.split("/")[-1]
+            row_len = score.shape[-1]
+            valid, thres, kept, rows = _select(score, float(r), row_len=row_len)
+            want = np.unpackbits(g[f"{tag}/valid/{r}"])[:score.numel()].astype(bool)
+            assert np.array_equal(valid.numpy().reshape(-1), want), (tag, r)
+            assert thres == g[f"{tag}/thres/{r}"][0], (tag, r)
+            assert kept == int(want.sum())
+            assert np.array_equal(rows.numpy(), want.reshape(-1, row_len).sum(-1).astype(np.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(28, 1, 4, 4096), (3, 1, 2, 1000), (1, 1, 1, 13)])
+def test_select_threshold_vs_oracle(dtype, shape):
+    g = torch.Generator().manual_seed(sum(shape) + (1 if dtype == torch.bfloat16 else 0))
+    score = (torch.rand(shape, generator=g) ** 6).to(dtype)
+    for ratio in (0.0, 0.05, 0.3, 0.5, 0.97, 1.0):
+        want_v, want_t = orc.threshold(score, ratio)
+        valid, thres, kept, rows = _select(score, ratio, row_len=shape[-1])
+        assert torch.equal(valid, want_v), (dtype, shape, ratio)
+        assert thres == want_t
+        assert kept == int(want_v.sum())
+        assert torch.equal(rows, want_v.view(-1, shape[-1]).sum(-1).int())
+
+
+def test_select_threshold_signs_and_zeros():
+    score = torch.tensor([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.0, 65504.0, -65504.0, 6e-8, -6e-8, 0.0],
+                         dtype=torch.float16).view(1, 1, 1, -1)
+    for ratio in (0.0, 0.2, 0.34, 0.5, 0.75, 0.99):
+        want_v, want_t = orc.threshold(score, ratio)
+        valid, thres, kept, _ = _select(score, ratio)
+        assert torch.equal(valid, want_v), ratio
+        assert thres == want_t, ratio  # note 0.0 == -0.0
+
+
+def test_select_head_level_known_answers():
+    """config 5: head-level scores of utils/head_score (qwen2.5-14b at ratio 0.6 keeps 229/384 heads)."""
+    g = load_golden("g4_head_score.npz")
+    for name in ("qwen2.5-14b", "qwen2.5-7b", "llama3.1-8b"):
+        hs = from_bits(g[f"{name}/head_score"], bool(g[f"{name}/is_bf16"][0]))
+        for ctx_len in (64, 1000):
+            score = hs.unsqueeze(-1).expand(-1, -1, ctx_len).unsqueeze(1).contiguous()
+            for r in (0.3, 0.6, 0.9):
+                valid, thres, kept, rows = _select(score, r, row_len=ctx_len)
+                want = g[f"{name}/kept/{ctx_len}/{r!r}"]
+                assert np.array_equal(valid[:, 0, :, 0].numpy(), want)
+                assert thres == g[f"{name}/thres/{ctx_len}/{r!r}"][0]
+                assert np.array_equal(rows.view(want.shape).numpy(), want.astype(np.int32) * ctx_len)
+
+
+def test_select_full_size_properties():
+    """BASELINE size (Qwen2.5-7B @128k: 28*4*131072 scores): size-independent properties."""
+    L, Hkv, N = 28, 4, 131072
+    g = torch.Generator(device=DEV).manual_seed(0)
+    score = (torch.rand((L, 1, Hkv, N), generator=g, device=DEV) ** 8).to(torch.float16)
+    valid, thres, kept, rows = ops().select_threshold(score, 0.3, row_len=N)
+    t = thres.item()
+    n = score.numel()
+    idx = max(int(n * 0.3) - 1, 0)
+    # (1) mask == (score > thres); (2) thres is an order statistic: #(> thres) <= idx < #(>= thres)
+    assert torch.equal(valid, score.float() > t)
+    gt = int((score.float() > t).sum())
+    ge = int((score.float() >= t).sum())
+    assert gt <= idx < ge
+    assert int(kept.item()) == gt and int(rows.sum()) == gt
+    assert torch.equal(rows.view(L, Hkv).long(), valid.view(L, Hkv, N).sum(-1))
+    # idempotence: selecting again on the same scores gives the same mask
+    valid2, thres2, _, _ = ops().select_threshold(score, 0.3, row_len=N)
+    assert torch.equal(valid, valid2) and thres2.item() == t
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 uniform top-k
+# ------------------------------------------------------------------------------------------------
+def test_select_topk_rows_golden():
+    g = load_golden("g3_threshold_uniform.npz")
+    score = from_bits(g["score"], False)
+    N = score.shape[-1]
+    for key in [k for k in g.files if k.startswith("valid/")]:
+        r = float(key.split("/")[1])
+        k = int(N * r) if r < 1 else N
+        valid, counts = ops().select_topk_rows(score.to(DEV), k)
+        want = np.unpackbits(g[key])[:score.numel()].astype(bool)
+        assert np.array_equal(valid.cpu().numpy().reshape(-1), want), r
+        assert (counts.cpu() == k).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_select_topk_rows_ties_vs_oracle(dtype):
+    g = torch.Generator().manual_seed(11)
+    score = (torch.rand((4, 1, 3, 3001), generator=g) ** 3).to(dtype)  # bf16: heavy ties
+    for ratio in (0.01, 0.3, 0.77):
+        want, _ = orc.threshold_uniform([score[i] for i in range(4)], ratio)
+        k = int(3001 * ratio)
+        valid, counts = ops().select_topk_rows(score.to(DEV), k)
+        assert torch.equal(valid.cpu(), want)
+        assert (valid.cpu().view(-1, 3001).sum(-1) == k).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# a8/a9 compaction
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f16_pair", "bf16_pair", "f16_uniform"])
+@pytest.mark.parametrize("batched", [False, True])
+def test_compact_golden(tag, batched):
+    g = load_golden(f"g6_cache_{tag}.npz")
+    L, H, Hkv, D, sink, N, bf = g["meta"].tolist()
+    K = [from_bits(g[f"K0/{l}"], bf).to(DEV) for l in range(L)]
+    V = [from_bits(g[f"V0/{l}"], bf).to(DEV) for l in range(L)]
+    valid = torch.from_numpy(g["valid"]).to(DEV)
+    plan = ops().compact_plan(valid, sink, sink + N, slack=0)
+    meta = plan.meta.cpu()
+    torch.cuda.synchronize()
+    len_k = plan.len_k.cpu()
+    for l in range(L):
+        assert np.array_equal(len_k[l].numpy(), g[f"len_k/{l}"])
+        assert np.array_equal(plan.cu_len_k[l].cpu().numpy(), g[f"cu_len_k/{l}"])
+        assert int(plan.max_len_k[l]) == int(g[f"max_len_k/{l}"][0])
+        assert np.array_equal(plan.seg_start[l].cpu().numpy(), g[f"cu_len_k/{l}"][:-1])
+    totals = len_k.sum(-1).tolist()
+    if batched:
+        ko, vo = ops().compact_layers(K, V, plan, totals)
+    else:
+        ko, vo = zip(*[ops().compact_layer(K[l], V[l], plan, l, totals[l]) for l in range(L)])
+    for l in range(L):
+        assert np.array_equal(to_bits(ko[l]), g[f"flatK/{l}"])
+        assert np.array_equal(to_bits(vo[l]), g[f"flatV/{l}"])
+
+
+@pytest.mark.parametrize("dtype,D", [(torch.float16, 128), (torch.bfloat16, 128), (torch.float16, 64)])
+@pytest.mark.parametrize("slack", [0, 37])
+def test_compact_vs_oracle_ragged(dtype, D, slack):
+    """ragged masks incl. an empty head, a full head, tile-straddling runs, sink and trailing rows, head stride
+    larger than klen*D (views into a cache with spare capacity)."""
+    L, Hkv, sink, N, extra = 2, 3, 5, 2500, 9
+    klen = sink + N + extra
+    cap = klen + 100
+    g = torch.Generator().manual_seed(D + slack)
+    store_k = [torch.randn(1, Hkv, cap, D, generator=g).to(dtype) for _ in range(L)]
+    store_v = [torch.randn(1, Hkv, cap, D, generator=g).to(dtype) for _ in range(L)]
+    valid = torch.rand(L, 1, Hkv, N, generator=g) < 0.3
+    valid[0, 0, 0] = False
+    valid[1, 0, 2] = True
+    valid[1, 0, 1, 1000:1100] = True
+    K = [s[:, :, :klen] for s in store_k]
+    V = [s[:, :, :klen] for s in store_v]
+    fk, fv, lens, cus, mxs = orc.prepare_init([k.contiguous() for k in K], [v.contiguous() for v in V], valid, sink)
+    Kd = [s.to(DEV)[:, :, :klen] for s in store_k]
+    Vd = [s.to(DEV)[:, :, :klen] for s in store_v]
+    plan = ops().compact_plan(valid.to(DEV), sink, klen, slack=slack)
+    len_k = plan.len_k.cpu()
+    for l in range(L):
+        assert torch.equal(len_k[l], lens[l])
+        assert torch.equal(plan.cu_len_k[l].cpu(), cus[l])
+        assert int(plan.max_len_k[l]) == int(mxs[l])
+    totals = (len_k.sum(-1) + slack * Hkv).tolist()
+    ko, vo = ops().compact_layers(Kd, Vd, plan, totals)
+    seg = plan.seg_start.cpu()
+    for l in range(L):
+        for h in range(Hkv):
+            a, n = int(seg[l, h]), int(len_k[l, h])
+            c = int(cus[l][h])
+            assert torch.equal(ko[l][a:a + n].cpu(), fk[l][c:c + n])
+            assert torch.equal(vo[l][a:a + n].cpu(), fv[l][c:c + n])
+
+
+def test_compact_all_kept_and_none_kept():
+    L, Hkv, sink, N, D = 1, 2, 0, 1024, 128
+    k = torch.randn(1, Hkv, N, D).half().to(DEV)
+    v = torch.randn(1, Hkv, N, D).half().to(DEV)
+    for fill in (True, False):
+        valid = torch.full((L, 1, Hkv, N), fill, dtype=torch.bool, device=DEV)
+        plan = ops().compact_plan(valid, sink, N)
+        tot = int(plan.len_k.sum())
+        assert tot == (Hkv * N if fill else 0)
+        ko, vo = ops().compact_layer(k, v, plan, 0, tot)
+        if fill:
+            assert torch.equal(ko, k.view(-1, D)) and torch.equal(vo, v.view(-1, D))
+
+
+# ------------------------------------------------------------------------------------------------
+# a10/a11 append
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("t", [1, 7])
+def test_update_flatten_view_vs_oracle(dtype, t):
+    Hkv, D = 4, 128
+    g = torch.Generator().manual_seed(t)
+    lens = torch.tensor([5, 0, 133, 40], dtype=torch.int32)
+    offset = 3
+    head_lens = lens + offset
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), head_lens.cumsum(0).int()])
+    cache = torch.randn(int(cu[-1]), D, generator=g).to(dtype)
+    state = torch.randn(Hkv * t, D, generator=g).to(dtype)
+    want = orc.update_flatten_view(cache, state, head_lens, cu)
+    got = ops().update_flatten_view(cache.to(DEV), state.to(DEV), head_lens.to(DEV), cu.to(DEV))
+    assert torch.equal(got.cpu(), want)
+
+
+def test_update_flatten_view_dtype_checks():
+    o = ops()
+    cache = torch.zeros(4, 128, dtype=torch.float16, device=DEV)
+    state = torch.zeros(2, 128, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="headlens to be int32"):
+        o.update_flatten_view(cache, state, torch.tensor([2, 2], device=DEV), torch.tensor([0, 2, 4], dtype=torch.int32, device=DEV))
+    with pytest.raises(RuntimeError, match="divisible"):
+        o.update_flatten_view(cache, torch.zeros(3, 128, dtype=torch.float16, device=DEV),
+                              torch.tensor([2, 2], dtype=torch.int32, device=DEV),
+                              torch.tensor([0, 2, 4], dtype=torch.int32, device=DEV))
+
+
+def test_append_inplace_matches_rebuild():
+    """O(t) slack append == the reference's out-of-place rebuild, head by head."""
+    Hkv, D, slack = 3, 128, 16
+    g = torch.Generator().manual_seed(5)
+    lens = torch.tensor([7, 0, 50], dtype=torch.int32)
+    seg = torch.tensor([0, 7 + slack, 7 + slack + 0 + slack], dtype=torch.int32)
+    total = int(lens.sum()) + Hkv * slack
+    kc = torch.randn(total, D, generator=g).half().to(DEV)
+    vc = torch.randn(total, D, generator=g).half().to(DEV)
+    kc0, vc0 = kc.clone(), vc.clone()
+    cur = lens.clone().to(DEV)
+    for t in (5, 1, 1):
+        ks = torch.randn(1, Hkv, t, D, generator=g).half().to(DEV)
+        vs = torch.randn(1, Hkv, t, D, generator=g).half().to(DEV)
+        ops().append_inplace(kc, vc, ks, vs, seg.to(DEV), cur)
+        for h in range(Hkv):
+            a = int(seg[h]) + int(cur[h])
+            assert torch.equal(kc[a:a + t], ks[0, h]) and torch.equal(vc[a:a + t], vs[0, h])
+        cur += t
+    for h in range(Hkv):  # untouched prefix
+        a, n = int(seg[h]), int(lens[h])
+        assert torch.equal(kc[a:a + n], kc0[a:a + n]) and torch.equal(vc[a:a + n], vc0[a:a + n])
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 scoring
+# ------------------------------------------------------------------------------------------------
+G1 = load_golden("g1_score.npz")
+
+
+def _score_stats(got, want):
+    d = ulp_diff(got, want)
+    return float((d == 0).float().mean()), float((d <= 1).float().mean()), int(d.max())
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in G1.files}))
+def test_score_chunk_golden(name):
+    """Tolerance (north_star: scores feed an integer-exact selection; masks are bit-exact GIVEN the scores):
+    the kernel follows the reference's rounding chain; differences come only from fp32 accumulation order
+    inside the MFMA and the exp/log implementation: >= 97% of scores bit-identical, >= 99.5% within 1 half-ulp,
+    none beyond 8 half-ulps (a 1-ulp flip of a LOGIT moves the probability by several ulps)."""
+    Hkv, G, D, sink, start, end, q_len, klen, bf = G1[name + "/meta"].tolist()
+    q = from_bits(G1[name + "/q"], bf).to(DEV)
+    k = from_bits(G1[name + "/k"], bf).to(DEV)
+    want = from_bits(G1[name + "/score"], bf)
+    got = ops().score_chunk(q, k, sink, start, end).cpu()
+    assert got.shape == want.shape
+    exact, within1, worst = _score_stats(got, want)
+    assert exact >= 0.97 and within1 >= 0.995 and worst <= 8, (exact, within1, worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_score_chunk_vs_oracle_multi_tile(dtype):
+    """shapes that exercise several 128-row tiles, ragged tails, a head stride with slack and G=7."""
+    Hkv, G, D, sink, N, q_len = 2, 7, 128, 32, 700, 413
+    start, end = sink + 150, sink + 550
+    klen, cap = sink + N + q_len, sink + N + q_len + 64
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(1, Hkv * G, q_len, D, generator=g).to(dtype)
+    kstore = torch.randn(1, Hkv, cap, D, generator=g).to(dtype)
+    want = orc.get_score(q, kstore[:, :, :klen].contiguous(), sink, start, end)
+    got = ops().score_chunk(q.to(DEV), kstore.to(DEV)[:, :, :klen], sink, start, end).cpu()
+    exact, within1, worst = _score_stats(got, want)
+    assert exact >= 0.97 and within1 >= 0.995 and worst <= 8, (exact, within1, worst)
+
+
+def test_score_then_select_end_to_end_hamming():
+    """End to end: masks from HIP scores vs masks from oracle scores — Hamming distance reported and bounded."""
+    Hkv, G, D, sink, N, q_len = 2, 4, 128, 16, 512, 270
+    klen = sink + N + q_len
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(1, Hkv * G, q_len, D, generator=g).half()
+    k = torch.randn(1, Hkv, klen, D, generator=g).half()
+    want = orc.get_score(q, k, sink, sink, sink + N)
+    got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, sink, sink + N)
+    v_ref, _ = orc.threshold(want, 0.3)
+    v_hip, _, _, _ = ops().select_threshold(got, 0.3)
+    ham = float((v_ref != v_hip.cpu()).float().mean())
+    print(f"end-to-end mask Hamming distance: {ham:.2e}")
+    assert ham <= 5e-3
+    # and the contract that matters: on the ORACLE's scores the HIP mask is bit-exact
+    v_hip2, _, _, _ = ops().select_threshold(want.to(DEV), 0.3)
+    assert torch.equal(v_hip2.cpu(), v_ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# a13 variable-length attention   (tolerance from north_star: 1e-3 absolute in fp16)
+# ------------------------------------------------------------------------------------------------
+G7 = load_golden("g7_attn.npz")
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in G7.files}))
+def test_varlen_attn_golden(name):
+    Hkv, G, D, q_len, bf = G7[name + "/meta"].tolist()
+    q = from_bits(G7[name + "/q"], bf).to(DEV)
+    k = from_bits(G7[name + "/k"], bf).to(DEV)
+    v = from_bits(G7[name + "/v"], bf).to(DEV)
+    ks = torch.from_numpy(G7[name + "/k_start"]).to(DEV)
+    kl = torch.from_numpy(G7[name + "/k_len"]).to(DEV)
+    want = from_bits(G7[name + "/out"], bf).float()
+    got = ops().varlen_attn(q, k, v, ks, kl, q_len, int(kl.max()), causal=True).cpu().float()
+    tol = 1e-3 if not bf else 8e-3  # bf16 output spacing is 2^-8 relative
+    assert (got - want).abs().max() <= tol, float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("q_len", [1, 5])
+def test_varlen_attn_long_ragged_vs_oracle(q_len):
+    Hkv, G, D = 4, 7, 128
+    lens = [4097, 33, 1500, 0 + q_len]
+    g = torch.Generator().manual_seed(q_len)
+    starts, tot = [], 0
+    for ln in lens:
+        starts.append(tot)
+        tot += ln + 3
+    q = torch.randn(Hkv * q_len, G, D, generator=g).half()
+    k = torch.randn(tot, D, generator=g).half()
+    v = torch.randn(tot, D, generator=g).half()
+    want = orc.varlen_attn(q, k, v, starts, lens, q_len).float()
+    got = ops().varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), torch.tensor(starts, dtype=torch.int32, device=DEV),
+                            torch.tensor(lens, dtype=torch.int32, device=DEV), q_len, max(lens)).cpu().float()
+    assert (got - want).abs().max() <= 1e-3
+
+
+def test_varlen_attn_compaction_identity():
+    """compact + varlen attention == dense attention over the full KV with evicted keys masked (a13 anchor)."""
+    Hkv, G, D, klen, q_len = 2, 7, 128, 777, 3
+    g = torch.Generator().manual_seed(8)
+    k = torch.randn(1, Hkv, klen, D, generator=g).half()
+    v = torch.randn(1, Hkv, klen, D, generator=g).half()
+    q = torch.randn(Hkv * q_len, G, D, generator=g).half()
+    valid = (torch.rand(1, 1, Hkv, klen - q_len, generator=g) < 0.35)
+    plan = ops().compact_plan(valid.to(DEV), 0, klen)
+    tot = int(plan.len_k.sum())
+    ko, vo = ops().compact_layer(k.to(DEV), v.to(DEV), plan, 0, tot)
+    got = ops().varlen_attn(q.to(DEV), ko, vo, plan.seg_start[0], plan.len_k[0], q_len, int(plan.max_len_k[0])).cpu()
+    full = orc.get_valid(valid[0], 0, klen)[0]
+    want = orc.dense_masked_attn(q, k[0], v[0], full, q_len)
+    assert (got.float() - want.float()).abs().max() <= 1e-3

@@ -1,0 +1,79 @@
+// probe_layouts.hip — one-off hardware probe (gfx950): verifies the MFMA fragment layouts and the
+// ds_read_b64_tr_b16 semantics the kernels rely on.  Build: hipcc --offload-arch=gfx950 -O2 probe_layouts.hip -o probe_layouts
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__global__ void k32(const _Float16* A, const _Float16* B, float* C) {  // A[32][16], B[32][16] (cols x k), C[32][32]
+    int l = threadIdx.x;
+    h8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = A[(l & 31) * 16 + (l >> 5) * 8 + j]; b[j] = B[(l & 31) * 16 + (l >> 5) * 8 + j]; }
+    f16v acc = {0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        C[row * 32 + col] = acc[r];
+    }
+}
+__global__ void k16(const _Float16* A, const _Float16* B, float* C) {  // A[16][32], B[16][32], C[16][16]
+    int l = threadIdx.x;
+    h8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = A[(l & 15) * 32 + (l >> 4) * 8 + j]; b[j] = B[(l & 15) * 32 + (l >> 4) * 8 + j]; }
+    f4v acc = {0};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        C[row * 16 + col] = acc[r];
+    }
+}
+// tr read: LDS holds u16 values lds[i] = i.  Lane t supplies address of 4 consecutive u16.
+__global__ void ktr(unsigned short* out, int mode) {
+    __shared__ unsigned short lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (unsigned short)i;
+    __syncthreads();
+    int l = threadIdx.x;
+    int t = l & 15, g = l >> 4;
+    int addr;
+    if (mode == 0) addr = g * 64 + (t >> 2) * 16 + (t & 3) * 4;   // 4x16 row-major block per 16-lane group
+    else addr = g * 256 + t * 4;                                   // lane-linear 8-byte segments
+    s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lds + addr));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
+}
+int main() {
+    _Float16 hA[32 * 16], hB[32 * 16];
+    float hC[32 * 32];
+    for (int i = 0; i < 32; ++i) for (int k = 0; k < 16; ++k) { hA[i * 16 + k] = (_Float16)((i * 3 + k * 7) % 11 - 5); hB[i * 16 + k] = (_Float16)((i * 5 + k * 2) % 13 - 6); }
+    _Float16 *dA, *dB; float* dC;
+    hipMalloc(&dA, sizeof(hA)); hipMalloc(&dB, sizeof(hB)); hipMalloc(&dC, sizeof(hC));
+    hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+    k32<<<1, 64>>>(dA, dB, dC);
+    hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) { float r = 0; for (int k = 0; k < 16; ++k) r += (float)hA[i * 16 + k] * (float)hB[j * 16 + k]; if (fabsf(r - hC[i * 32 + j]) > 1e-3) ++bad; }
+    printf("mfma_32x32x16_f16 layout: %s (bad=%d)\n", bad ? "FAIL" : "PASS", bad);
+    // 16x16x32
+    _Float16 gA[16 * 32], gB[16 * 32]; float gC[256];
+    for (int i = 0; i < 16; ++i) for (int k = 0; k < 32; ++k) { gA[i * 32 + k] = (_Float16)((i * 3 + k * 7) % 11 - 5); gB[i * 32 + k] = (_Float16)((i * 5 + k * 2) % 13 - 6); }
+    hipMemcpy(dA, gA, sizeof(gA), hipMemcpyHostToDevice); hipMemcpy(dB, gB, sizeof(gB), hipMemcpyHostToDevice);
+    k16<<<1, 64>>>(dA, dB, dC);
+    hipMemcpy(gC, dC, sizeof(gC), hipMemcpyDeviceToHost);
+    bad = 0;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { float r = 0; for (int k = 0; k < 32; ++k) r += (float)gA[i * 32 + k] * (float)gB[j * 32 + k]; if (fabsf(r - gC[i * 16 + j]) > 1e-3) ++bad; }
+    printf("mfma_16x16x32_f16 layout: %s (bad=%d)\n", bad ? "FAIL" : "PASS", bad);
+    unsigned short* dO; unsigned short hO[256];
+    hipMalloc(&dO, sizeof(hO));
+    for (int mode = 0; mode < 2; ++mode) {
+        ktr<<<1, 64>>>(dO, mode);
+        hipMemcpy(hO, dO, sizeof(hO), hipMemcpyDeviceToHost);
+        printf("tr16_b64 mode %d:\n", mode);
+        for (int l = 0; l < 64; ++l) { printf("  lane %2d: %4d %4d %4d %4d\n", l, hO[l * 4], hO[l * 4 + 1], hO[l * 4 + 2], hO[l * 4 + 3]); }
+    }
+    hipError_t e = hipDeviceSynchronize();
+    printf("status: %s\n", hipGetErrorString(e));
+    return 0;
+}
