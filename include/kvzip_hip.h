@@ -151,11 +151,13 @@ int kvz_update_flatten_view(const void* cache, const void* state,
                             void* out, kvz_stream_t stream);
 
 /* a10 (MI355X layout)  O(t) in-place append into per-head slack:
- *   cache[seg_start[h] + cur_len[h] + i, :] = state[h, i, :]    i in [0,t)
+ *   cache[seg_start[h] + base_len[h] + len_offset + i, :] = state[h, i, :]    i in [0,t)
+ * base_len is the device-resident len_k of the pruned cache; len_offset is the reference's host-side
+ * info["offset"][layer] (attention/kvcache.py:58), so no device-side bookkeeping is needed per token.
  * state rows contiguous, head stride state_head_stride elements. Both K and V in one launch. */
 int kvz_append_inplace(void* k_cache, void* v_cache,
                        const void* k_state, const void* v_state, int64_t state_head_stride,
-                       const int32_t* seg_start, const int32_t* cur_len,
+                       const int32_t* seg_start, const int32_t* base_len, int len_offset,
                        int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
@@ -164,14 +166,14 @@ int kvz_append_inplace(void* k_cache, void* v_cache,
  *
  * Every KV head is one ragged "sequence"; its G query heads are MQA heads.
  *   q   : [Hkv*q_len, G, D]   (row = h*q_len + i)
- *   k,v : [rows, D]; head h owns rows k_start[h] .. k_start[h]+k_len[h]
+ *   k,v : [rows, D]; head h owns rows k_start[h] .. k_start[h]+len_h,  len_h = k_len[h] + k_len_offset
  *   out : [Hkv*q_len, G, D]
- *   causal (bottom-right aligned): query i sees key j iff j <= i + (k_len[h] - q_len)
+ *   causal (bottom-right aligned): query i sees key j iff j <= i + (len_h - q_len)
  *   P = softmax(q.k^T * scale) in fp32, out = P.v rounded to half
  * ------------------------------------------------------------------------- */
 size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k);
 int kvz_varlen_attn(const void* q, const void* k, const void* v,
-                    const int32_t* k_start, const int32_t* k_len,
+                    const int32_t* k_start, const int32_t* k_len, int k_len_offset,
                     int Hkv, int G, int q_len, int D, int max_len_k,
                     float scale, int causal, int dtype,
                     void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);

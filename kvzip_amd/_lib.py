@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede loading libkvzip_hip.so: torch bundles its own libamdhip64.so.7 and both
+# must share ONE HIP runtime (streams and device pointers cross the boundary).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkvzip_hip.so")
 
@@ -28,9 +31,9 @@ SIGNATURES = {
     "kvz_compact_layer": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_compact_layers": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

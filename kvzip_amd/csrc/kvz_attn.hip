@@ -51,12 +51,12 @@ template <int D> struct AttnCfg {
 template <typename T, int D>
 __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const int32_t* __restrict__ k_start,
-    const int32_t* __restrict__ k_len, int G, int q_len, int chunk, float scale, int causal,
+    const int32_t* __restrict__ k_len, int k_len_offset, int G, int q_len, int chunk, float scale, int causal,
     float* __restrict__ part_o, float* __restrict__ part_ml, int n_splits, int n_rtiles) {
     typedef AttnCfg<D> C;
     typedef typename HalfTraits<T>::v8 v8;
     const int split = blockIdx.x, h = blockIdx.y, rt = blockIdx.z;
-    const int len = k_len[h];
+    const int len = k_len[h] + k_len_offset;
     const int c0 = split * chunk;
     if (c0 >= len) return;
     const int c1 = min(len, c0 + chunk);
@@ -215,12 +215,13 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
 template <typename T, int D>
 __global__ __launch_bounds__(AT_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
                                                                         const float* __restrict__ part_ml,
-                                                                        const int32_t* __restrict__ k_len, int G,
+                                                                        const int32_t* __restrict__ k_len,
+                                                                        int k_len_offset, int G,
                                                                         int q_len, int chunk, int n_splits,
                                                                         int n_rtiles, T* __restrict__ out) {
     const int h = blockIdx.x, rt = blockIdx.y;
     const int R = q_len * G;
-    const int len = k_len[h];
+    const int len = k_len[h] + k_len_offset;
     const int nsp = (len + chunk - 1) / chunk;
     const int rows = min(AT_RT, R - rt * AT_RT);
     const int64_t base = ((int64_t)h * n_rtiles + rt) * n_splits * AT_RT;
@@ -250,8 +251,8 @@ static inline int attn_chunk(int Hkv, int max_len_k) {
 }
 
 template <typename T, int D>
-static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len, int Hkv,
-                       int G, int q_len, int max_len_k, float scale, int causal, void* out, void* ws,
+static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len,
+                       int k_len_offset, int Hkv, int G, int q_len, int max_len_k, float scale, int causal, void* out, void* ws,
                        hipStream_t stream) {
     const int chunk = attn_chunk(Hkv, max_len_k);
     const int n_splits = (max_len_k + chunk - 1) / chunk > 0 ? (max_len_k + chunk - 1) / chunk : 1;
@@ -260,10 +261,10 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
     float* part_ml = part_o + (size_t)Hkv * n_rtiles * n_splits * AT_RT * D;
     hipLaunchKernelGGL((varlen_attn_split_kernel<T, D>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
                        reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
-                       k_start, k_len, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
+                       k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
     KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
     hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles), dim3(AT_THREADS), 0, stream, part_o,
-                       part_ml, k_len, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
+                       part_ml, k_len, k_len_offset, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
     KVZ_CHECK_LAUNCH("varlen_attn_combine_kernel");
     return KVZ_OK;
 }
@@ -282,7 +283,8 @@ extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int
 }
 
 extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, const int32_t* k_start,
-                               const int32_t* k_len, int Hkv, int G, int q_len, int D, int max_len_k, float scale,
+                               const int32_t* k_len, int k_len_offset, int Hkv, int G, int q_len, int D,
+                               int max_len_k, float scale,
                                int causal, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && v && k_start && k_len && out && ws, KVZ_EINVAL, "kvz_varlen_attn: null pointer");
@@ -294,9 +296,9 @@ extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, cons
     KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
                 "kvz_varlen_attn: workspace too small");
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
-        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
     }
-    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
-    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
 }

@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256) void append_inplace_kernel(char* __restrict__ 
                                                             const char* __restrict__ ks, const char* __restrict__ vs,
                                                             int64_t state_head_stride_bytes,
                                                             const int32_t* __restrict__ seg_start,
-                                                            const int32_t* __restrict__ cur_len, int t, int row_bytes) {
+                                                            const int32_t* __restrict__ base_len, int len_offset,
+                                                            int t, int row_bytes) {
     const int h = blockIdx.y;
-    const int64_t dst_row0 = (int64_t)seg_start[h] + cur_len[h];
+    const int64_t dst_row0 = (int64_t)seg_start[h] + base_len[h] + len_offset;
     const int64_t chunks = (int64_t)t * row_bytes / 16;
     const u32x4* k_src = reinterpret_cast<const u32x4*>(ks + (int64_t)h * state_head_stride_bytes);
     const u32x4* v_src = reinterpret_cast<const u32x4*>(vs + (int64_t)h * state_head_stride_bytes);
@@ -338,9 +339,9 @@ extern "C" int kvz_update_flatten_view(const void* cache, const void* state, con
 }
 
 extern "C" int kvz_append_inplace(void* k_cache, void* v_cache, const void* k_state, const void* v_state,
-                                  int64_t state_head_stride, const int32_t* seg_start, const int32_t* cur_len, int Hkv,
-                                  int t, int D, int elem_bytes, kvz_stream_t stream_) {
-    KVZ_REQUIRE(k_cache && v_cache && k_state && v_state && seg_start && cur_len, KVZ_EINVAL,
+                                  int64_t state_head_stride, const int32_t* seg_start, const int32_t* base_len,
+                                  int len_offset, int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream_) {
+    KVZ_REQUIRE(k_cache && v_cache && k_state && v_state && seg_start && base_len, KVZ_EINVAL,
                 "kvz_append_inplace: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && t > 0, KVZ_EINVAL, "kvz_append_inplace: bad shape");
     const int rb = D * elem_bytes;
@@ -354,7 +355,7 @@ extern "C" int kvz_append_inplace(void* k_cache, void* v_cache, const void* k_st
     hipLaunchKernelGGL(append_inplace_kernel, dim3(bx, Hkv), dim3(256), 0, (hipStream_t)stream_,
                        reinterpret_cast<char*>(k_cache), reinterpret_cast<char*>(v_cache),
                        reinterpret_cast<const char*>(k_state), reinterpret_cast<const char*>(v_state),
-                       state_head_stride * elem_bytes, seg_start, cur_len, t, rb);
+                       state_head_stride * elem_bytes, seg_start, base_len, len_offset, t, rb);
     KVZ_CHECK_LAUNCH("append_inplace_kernel");
     return KVZ_OK;
 }

@@ -1,0 +1,379 @@
+"""KV caches with eviction — host-side mirror of the reference's ``EvictCache`` / ``RetainCache``
+(reference attention/kvcache.py:14-347): same constructor, hooks (``update / _get_score / prepare``), user
+calls (``prune / slice / init_score / get_seq_length / _mem``) and attributes; the data path runs in the
+HIP kernels of ``include/kvzip_hip.h``.
+
+MI355X-first storage (sized for 288 GB of HBM3E):
+  * before pruning every layer owns ONE ``[1, Hkv, capacity, D]`` buffer; ``update`` writes the new rows in
+    place (the reference re-allocates with ``torch.cat`` on every call, kvcache.py:75-78) and
+    ``key_cache[l]`` is a view of the filled part;
+  * ``prune`` compacts all layers in one launch into head-major ragged buffers; with ``layout="slack"``
+    (default) every head segment is followed by ``slack`` free rows so that appending the query / generated
+    tokens is O(t) and ``slice`` is O(1) (the reference rebuilds the whole flattened cache per layer and
+    token through ``update_flatten_view``, kvcache.py:57-73); ``layout="packed"`` reproduces the reference's
+    packed ``cu_len_k`` layout and its out-of-place append bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .score import KVScore
+
+
+def _model_props(model, device, dtype):
+    cfg = model.config if hasattr(model, "config") else model
+    if device is None or dtype is None:
+        p = next(model.parameters())
+        device = p.device if device is None else device
+        dtype = p.dtype if dtype is None else dtype
+    return cfg, torch.device(device), dtype
+
+
+class _CacheBase(KVScore):
+    """State shared by EvictCache and RetainCache (reference kvcache.py:18-39 / :222-242)."""
+
+    def __init__(self, model, evict_range: Tuple[int, int], device=None, dtype=None, reserve: int = 4096):
+        KVScore.__init__(self)
+        cfg, self.device, self.dtype = _model_props(model, device, dtype)
+        self.n_layers = cfg.num_hidden_layers
+        self.n_heads = cfg.num_attention_heads
+        self.n_heads_kv = cfg.num_key_value_heads
+        self.n_group_kv = self.n_heads // self.n_heads_kv
+
+        self.start_idx, self.end_idx = evict_range
+        self.ctx_len = self.end_idx - self.start_idx
+        self.sink = self.start_idx  # retain initial KV pairs for system prompts
+        self.prefill_ids = None
+        self.ctx_ids = None
+
+        self.get_score = False  # indicator for KV scoring
+        self.pruned = False     # whether KV cache is pruned or not
+        self.valid = None
+        self.valid_pad = torch.ones((1, self.n_heads_kv, self.start_idx), dtype=torch.bool, device=self.device)
+
+        self.key_cache: List[torch.Tensor] = []
+        self.value_cache: List[torch.Tensor] = []
+        self._seen_tokens = 0
+        self._store_k: List[torch.Tensor] = []   # [1, Hkv, capacity, D] per layer (pre-prune storage)
+        self._store_v: List[torch.Tensor] = []
+        self._fill: List[int] = []               # rows in use per layer
+        self._reserve = int(reserve)
+
+    # -- dense (pre-prune) storage --------------------------------------------------------------
+    def _dense_append(self, layer_idx: int, key_states: torch.Tensor, value_states: torch.Tensor):
+        t = key_states.shape[-2]
+        if len(self._store_k) <= layer_idx:
+            _, Hkv, _, D = key_states.shape
+            cap = t + self._reserve
+            self._store_k.append(torch.empty((1, Hkv, cap, D), dtype=key_states.dtype, device=key_states.device))
+            self._store_v.append(torch.empty((1, Hkv, cap, D), dtype=value_states.dtype, device=value_states.device))
+            self._fill.append(0)
+            self.key_cache.append(None)
+            self.value_cache.append(None)
+        f = self._fill[layer_idx]
+        cap = self._store_k[layer_idx].shape[2]
+        if f + t > cap:  # amortised growth
+            new_cap = max(2 * cap, f + t + self._reserve)
+            for store in (self._store_k, self._store_v):
+                old = store[layer_idx]
+                new = torch.empty((1, old.shape[1], new_cap, old.shape[3]), dtype=old.dtype, device=old.device)
+                new[:, :, :f].copy_(old[:, :, :f])
+                store[layer_idx] = new
+        self._store_k[layer_idx][:, :, f:f + t].copy_(key_states)
+        self._store_v[layer_idx][:, :, f:f + t].copy_(value_states)
+        self._fill[layer_idx] = f + t
+        self.key_cache[layer_idx] = self._store_k[layer_idx][:, :, :f + t]
+        self.value_cache[layer_idx] = self._store_v[layer_idx][:, :, :f + t]
+
+    def _dense_slice(self, seen_token_prev: int):
+        for l in range(len(self._store_k)):
+            self._fill[l] = seen_token_prev
+            self.key_cache[l] = self._store_k[l][:, :, :seen_token_prev]
+            self.value_cache[l] = self._store_v[l][:, :, :seen_token_prev]
+
+    # reference: kvcache.py:108-112
+    def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
+        if len(self.key_cache) <= layer_idx:
+            return 0
+        return self._seen_tokens
+
+    # reference: kvcache.py:140-150
+    def _get_valid(self, layer_idx: int, n_seq: int) -> torch.Tensor:
+        """full mask ``[1, Hkv, n_seq]`` = ones(sink) ++ valid[layer] ++ ones(rest)  (debug / interop helper; the
+        kernels derive it on the fly)."""
+        valid = torch.cat([self.valid_pad, self.valid[layer_idx]], dim=-1)
+        size = list(valid.shape)
+        size[-1] = n_seq - valid.shape[-1]
+        ones = torch.ones(size, device=valid.device, dtype=torch.bool)
+        return torch.cat([valid, ones], dim=-1)
+
+    def _select(self, ratio: float, level: str):
+        """-> (valid [L,1,Hkv,N] bool, thres float, r_real float); one host synchronisation."""
+        if "uniform" in level:
+            self.valid, thres = self._threshold_uniform(self.score, ratio)
+            n = self.valid.numel()
+            k = int(self.valid.shape[-1] * ratio) if ratio < 1 else self.valid.shape[-1]
+            kept = k * (n // self.valid.shape[-1])
+        else:
+            score = self._stacked_score(self.score)
+            valid, thres_dev, kept_dev, _ = self._threshold_device(score, ratio)
+            self.valid = valid.view(score.shape)
+            host = torch.stack([thres_dev.double().squeeze(0), kept_dev.double().squeeze(0)]).cpu()  # one D2H sync
+            thres = float(host[0]) if ratio < 1 else 0.
+            kept = int(host[1])
+            n = self.valid.numel()
+        assert self.valid.size(-1) == self.ctx_len
+        # reference kvcache.py:133-134: rmv.float().mean() (fp32) -> 1 - python float
+        r_ = 1 - float(np.float32(n - kept) / np.float32(n))
+        self._evicted = n - kept
+        return thres, r_
+
+
+class EvictCache(_CacheBase):
+    """KV cache that evicts KV from the cache before decoding (reference attention/kvcache.py:14-213)."""
+
+    def __init__(self, model, evict_range: Tuple[int, int], device=None, dtype=None, layout: str = "slack",
+                 slack: int = 1024, reserve: int = 4096, verbose: bool = True):
+        super().__init__(model, evict_range, device=device, dtype=dtype, reserve=reserve)
+        assert layout in ("slack", "packed")
+        self.layout = layout
+        self.slack = int(slack) if layout == "slack" else 0
+        self.verbose = verbose
+        self.info: Dict[str, Any] = {"flatten": False, "offset": None}
+        self._attn_ws: Optional[torch.Tensor] = None
+
+    # reference: kvcache.py:41-80
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=dict()):
+        """Update KV cache and return (K, V) of the layer."""
+        if layer_idx == 0:
+            seen_token = (cache_kwargs or {}).get("seen_token", key_states.size(-2))
+            self._seen_tokens += seen_token
+
+        if not self.info["flatten"]:
+            self._dense_append(layer_idx, key_states, value_states)
+        elif self.layout == "slack":
+            t = key_states.size(-2)
+            off = self.info["offset"][layer_idx]
+            if off + t > self.slack:
+                self._grow_slack(off + t)
+            ops.append_inplace(self.key_cache[layer_idx], self.value_cache[layer_idx], key_states, value_states,
+                               self.info["seg_start"][layer_idx], self.info["len_k"][layer_idx], off)
+        else:  # packed: the reference's out-of-place rebuild (csrc/csrc/cuda_api.cu)
+            cu_klen = self.info["cu_len_k"][layer_idx]
+            head_lens = self.info["len_k"][layer_idx] + self.info["offset"][layer_idx]
+            dim = key_states.size(-1)
+            self.key_cache[layer_idx] = ops.update_flatten_view(
+                self.key_cache[layer_idx], key_states.contiguous().view(-1, dim), head_lens, cu_klen)
+            self.value_cache[layer_idx] = ops.update_flatten_view(
+                self.value_cache[layer_idx], value_states.contiguous().view(-1, dim), head_lens, cu_klen)
+        return self.key_cache[layer_idx], self.value_cache[layer_idx]
+
+    # reference: kvcache.py:82-106
+    def slice(self, seen_token_prev: int):
+        """Evict KV of queries and generated tokens from the cache (for the reuse of the context cache)."""
+        if not self.info["flatten"]:
+            self._dense_slice(seen_token_prev)
+        elif self.layout == "slack":
+            pass  # appended rows live in the slack: resetting the offsets below is all it takes
+        else:
+            for l in range(self.n_layers):
+                cu_klen = self.info["cu_len_k"][l].tolist()
+                head_lens = self.info["len_k_host"][l]
+                self.key_cache[l] = torch.cat(
+                    [self.key_cache[l][cu_klen[h]:cu_klen[h] + head_lens[h]] for h in range(self.n_heads_kv)])
+                self.value_cache[l] = torch.cat(
+                    [self.value_cache[l][cu_klen[h]:cu_klen[h] + head_lens[h]] for h in range(self.n_heads_kv)])
+                self.info["cu_len_k"][l] -= self.info["offset"][l] * self.info["cu_head"]
+        self.info["offset"] = [0 for _ in range(self.n_layers)]
+        self._seen_tokens = seen_token_prev
+
+    # reference: kvcache.py:114-121
+    def _mem(self) -> float:
+        """Memory usage of the cache in GB (rows in use, K + V)."""
+        mem = 0
+        for l in range(len(self.key_cache)):
+            if self.info["flatten"]:
+                rows = self.info["rows_used"][l] + self.n_heads_kv * self.info["offset"][l]
+                mem += rows * self.key_cache[l].shape[-1] * self.key_cache[l].element_size()
+            else:
+                mem += self.key_cache[l].numel() * self.key_cache[l].element_size()
+        return round(2 * mem / 10**9, 1)
+
+    # reference: kvcache.py:123-138
+    def prune(self, ratio: float, level: str = "pair"):
+        """Prune the KV cache.  -> (thres, real kept ratio)."""
+        thres, r_ = self._select(ratio, level)
+        self.prepare_init()
+        self.pruned = True
+        if self.verbose:
+            print(f"ratio {r_:.2f} ({level}), {self._mem()} GB (evict {self._evicted:.0f} pairs)")
+        return thres, r_
+
+    # reference: kvcache.py:152-185
+    def prepare_init(self):
+        """Evict KV and prepare the varlen metadata: one plan + one gather launch for all layers."""
+        L, Hkv = self.n_layers, self.n_heads_kv
+        klen = self.key_cache[0].shape[2]
+        plan = ops.compact_plan(self.valid, self.sink, klen, slack=self.slack)
+        meta = plan.meta.cpu()  # the single host sync of prepare_init
+        o = 0
+        len_h = meta[o:o + L * Hkv].view(L, Hkv); o += L * Hkv
+        o += L * Hkv
+        o += L * (Hkv + 1)
+        max_h = meta[o:o + L]
+        rows_used = len_h.sum(-1).tolist()
+        totals = [r + Hkv * self.slack for r in rows_used]
+        ks, vs = ops.compact_layers(self.key_cache, self.value_cache, plan, totals)
+        self.key_cache, self.value_cache = list(ks), list(vs)
+        self._store_k, self._store_v, self._fill = [], [], []  # release the dense storage
+        self._plan = plan
+        cu_head = torch.arange(Hkv + 1, dtype=torch.int32, device=self.device)
+        self.info = {
+            "flatten": True,
+            "layout": self.layout,
+            "cu_head": cu_head,
+            "len_k": [plan.len_k[l] for l in range(L)],          # kv lengths of heads in a layer (device int32)
+            "len_k_host": len_h.tolist(),
+            "max_len_k": [int(x) for x in max_h.tolist()],       # python ints: no per-step device sync
+            "cu_len_k": [plan.cu_len_k[l].clone() for l in range(L)],  # packed-layout cumulative lengths
+            "seg_start": [plan.seg_start[l] for l in range(L)],  # first row of each head segment
+            "rows_used": rows_used,
+            "offset": [0 for _ in range(L)],                     # rows appended after pruning, per layer
+        }
+
+    def _grow_slack(self, need: int):
+        """Re-lay out every layer with a larger slack (rare: only when more than ``slack`` tokens are appended)."""
+        new_slack = max(2 * self.slack, need + 256)
+        Hkv = self.n_heads_kv
+        for l in range(self.n_layers):
+            lens = self.info["len_k_host"][l]
+            off = self.info["offset"][l]
+            D = self.key_cache[l].shape[-1]
+            total = sum(lens) + Hkv * new_slack
+            nk = torch.empty((total, D), dtype=self.key_cache[l].dtype, device=self.device)
+            nv = torch.empty((total, D), dtype=self.value_cache[l].dtype, device=self.device)
+            old_start = self.info["seg_start"][l].tolist()
+            starts, acc = [], 0
+            for h in range(Hkv):
+                starts.append(acc)
+                n = lens[h] + off
+                nk[acc:acc + n].copy_(self.key_cache[l][old_start[h]:old_start[h] + n])
+                nv[acc:acc + n].copy_(self.value_cache[l][old_start[h]:old_start[h] + n])
+                acc += lens[h] + new_slack
+            self.key_cache[l], self.value_cache[l] = nk, nv
+            self.info["seg_start"][l] = torch.tensor(starts, dtype=torch.int32, device=self.device)
+        self.slack = new_slack
+
+    # reference: kvcache.py:187-213
+    def prepare(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                layer_idx: int):
+        """Flatten the queries for variable-length attention and bump the per-layer offsets."""
+        bsz, n_heads_q, q_len, dim = query_states.shape
+        cu_len_q = q_len * self.info["cu_head"]
+        if q_len == 1:
+            query_states = query_states.reshape(-1, self.n_group_kv, dim)  # pure view: [Hkv*1, G, D]
+        else:
+            query_states = query_states.view(bsz, self.n_heads_kv, self.n_group_kv, q_len, dim)
+            query_states = query_states.transpose(2, 3).contiguous().view(-1, self.n_group_kv, dim)
+
+        self.info["offset"][layer_idx] += q_len
+        info = {
+            "cu_len_q": cu_len_q,
+            "max_len_q": q_len,
+            "max_len_k": self.info["max_len_k"][layer_idx] + self.info["offset"][layer_idx],
+            # MI355X layout: segment starts + base lengths + host-side offset
+            "k_start": self.info["seg_start"][layer_idx],
+            "k_len": self.info["len_k"][layer_idx],
+            "k_len_offset": self.info["offset"][layer_idx],
+        }
+        if self.layout == "packed":
+            self.info["cu_len_k"][layer_idx] += cu_len_q
+            info["cu_len_k"] = self.info["cu_len_k"][layer_idx]
+            info["k_start"] = info["cu_len_k"][:-1]
+        else:
+            info["cu_len_k"] = None
+        return query_states, key_states.view(-1, 1, dim), value_states.view(-1, 1, dim), info
+
+    def attend(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor, info: dict,
+               causal: bool = True, softmax_scale: Optional[float] = None) -> torch.Tensor:
+        """Variable-length attention over the pruned cache: what the reference gets from
+        ``flash_attn_varlen_func`` (attention/attn.py:61-71).  Returns ``[Hkv*q_len, G, D]``."""
+        dim = query_states.shape[-1]
+        need = ops._lib.load().kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, info["max_len_q"],
+                                                               dim, info["max_len_k"])
+        if self._attn_ws is None or self._attn_ws.numel() < need:
+            self._attn_ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=query_states.device)
+        return ops.varlen_attn(query_states, key_states.view(-1, dim), value_states.view(-1, dim), info["k_start"],
+                               info["k_len"], info["max_len_q"], info["max_len_k"], causal=causal,
+                               softmax_scale=softmax_scale, workspace=self._attn_ws,
+                               k_len_offset=info["k_len_offset"])
+
+
+class RetainCache(_CacheBase):
+    """KV cache that keeps the full KV in memory and subsamples it at every attention call, so that several
+    compression ratios can be evaluated from a single prefill (reference attention/kvcache.py:216-347).
+    Produces the same flattened tensors as :class:`EvictCache` (the reference's internal cross-check)."""
+
+    def __init__(self, model, evict_range: Tuple[int, int], device=None, dtype=None, reserve: int = 4096,
+                 verbose: bool = True):
+        super().__init__(model, evict_range, device=device, dtype=dtype, reserve=reserve)
+        self.verbose = verbose
+        self._cu_head = torch.arange(self.n_heads_kv + 1, dtype=torch.int32, device=self.device)
+
+    # reference: kvcache.py:244-267
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=dict()):
+        if layer_idx == 0:
+            seen_token = (cache_kwargs or {}).get("seen_token", key_states.shape[-2])
+            self._seen_tokens += seen_token
+        self._dense_append(layer_idx, key_states, value_states)
+        return self.key_cache[layer_idx], self.value_cache[layer_idx]
+
+    # reference: kvcache.py:269-276
+    def slice(self, seen_token_prev: int):
+        assert len(self.key_cache[0].shape) == 4, "Cache at each layer should be 4D tensor"
+        self._dense_slice(seen_token_prev)
+        self._seen_tokens = seen_token_prev
+
+    # reference: kvcache.py:278-282
+    def _mem(self) -> float:
+        mem = self.n_layers * self.key_cache[0].numel() * self.key_cache[0].element_size()
+        return round(2 * mem / 10**9, 1)
+
+    # reference: kvcache.py:284-298
+    def prune(self, ratio: float, level: str = "pair"):
+        """Prune the KV cache (fake): only the mask is computed; it is applied before every attention."""
+        thres, r_ = self._select(ratio, level)
+        self.pruned = True
+        if self.verbose:
+            print(f"ratio {r_:.2f} ({level}), threshold {thres:.4f} (evict {self._evicted:.0f} pairs)")
+        return thres, r_
+
+    # reference: kvcache.py:312-347
+    def prepare(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                layer_idx: int):
+        bsz, n_heads_q, q_len, dim = query_states.shape
+        klen = key_states.size(2)
+        query_states = query_states.view(bsz, self.n_heads_kv, self.n_group_kv, q_len, dim)
+        query_states = query_states.transpose(2, 3).contiguous().view(-1, self.n_group_kv, dim)
+        cu_seqlens_q = q_len * self._cu_head
+
+        plan = ops.compact_plan(self.valid[layer_idx:layer_idx + 1], self.sink, klen, slack=0)
+        total = int(plan.cu_len_k[0, -1])  # host sync, as the reference's boolean indexing
+        k_flat, v_flat = ops.compact_layer(key_states, value_states, plan, 0, total)
+        info = {
+            "cu_len_q": cu_seqlens_q,
+            "cu_len_k": plan.cu_len_k[0],
+            "max_len_q": q_len,
+            "max_len_k": int(plan.max_len_k[0]),
+            "k_start": plan.seg_start[0],
+            "k_len": plan.len_k[0],
+            "k_len_offset": 0,
+        }
+        return query_states, k_flat.view(-1, 1, dim), v_flat.view(-1, 1, dim), info
+
+    attend = EvictCache.attend
+    _attn_ws = None

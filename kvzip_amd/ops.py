@@ -159,6 +159,8 @@ def compact_layer(k: torch.Tensor, v: torch.Tensor, plan: CompactPlan, layer: in
     assert k.stride(-1) == 1 and k.stride(-2) == D and v.stride() == k.stride()
     k_out = torch.empty((total_rows, D), dtype=k.dtype, device=k.device)
     v_out = torch.empty((total_rows, D), dtype=v.dtype, device=v.device)
+    if total_rows == 0:
+        return k_out, v_out
     valid_l = plan.valid.view(plan.layers, Hkv, plan.N)[layer]
     tb = plan.tile_base.view(plan.layers, Hkv * plan.ntiles)[layer]
     rc = lib.kvz_compact_layer(k.data_ptr(), v.data_ptr(), k.stride(1), valid_l.data_ptr(), tb.data_ptr(),
@@ -180,8 +182,9 @@ def compact_layers(ks: Sequence[torch.Tensor], vs: Sequence[torch.Tensor], plan:
     for k, v in zip(ks, vs):
         assert k.shape == ks[0].shape and v.shape == ks[0].shape
         assert k.stride(-1) == 1 and k.stride(-2) == D and k.stride(1) == hs and v.stride() == k.stride()
-    k_outs = [torch.empty((int(t), D), dtype=ks[0].dtype, device=dev) for t in totals]
-    v_outs = [torch.empty((int(t), D), dtype=ks[0].dtype, device=dev) for t in totals]
+    # (an all-evicted layer still gets a 1-row buffer so that its table entry is a valid pointer)
+    k_outs = [torch.empty((max(int(t), 1), D), dtype=ks[0].dtype, device=dev)[:int(t)] for t in totals]
+    v_outs = [torch.empty((max(int(t), 1), D), dtype=ks[0].dtype, device=dev)[:int(t)] for t in totals]
     table = torch.tensor([[t.data_ptr() for t in ks], [t.data_ptr() for t in vs],
                           [t.data_ptr() for t in k_outs], [t.data_ptr() for t in v_outs]],
                          dtype=torch.int64).to(dev, non_blocking=False)
@@ -223,13 +226,13 @@ def update_flatten_view(cache: torch.Tensor, state: torch.Tensor, headlens: torc
 
 
 def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.Tensor, v_state: torch.Tensor,
-                   seg_start: torch.Tensor, cur_len: torch.Tensor) -> None:
+                   seg_start: torch.Tensor, base_len: torch.Tensor, len_offset: int = 0) -> None:
     """O(t) append of ``k_state/v_state [1, Hkv, t, D]`` after each head's current rows (slack layout)."""
     lib = _lib.load()
     _, Hkv, t, D = k_state.shape
     assert k_state.stride(-1) == 1 and k_state.stride(-2) == D and v_state.stride() == k_state.stride()
     rc = lib.kvz_append_inplace(k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(), v_state.data_ptr(),
-                                k_state.stride(1), seg_start.data_ptr(), cur_len.data_ptr(), Hkv, t, D,
+                                k_state.stride(1), seg_start.data_ptr(), base_len.data_ptr(), int(len_offset), Hkv, t, D,
                                 k_cache.element_size(), _stream(k_cache))
     check(rc, "kvz_append_inplace")
 
@@ -239,7 +242,7 @@ def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.
 # --------------------------------------------------------------------------------------------------
 def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor,
                 q_len: int, max_len_k: int, causal: bool = True, softmax_scale: Optional[float] = None,
-                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, k_len_offset: int = 0) -> torch.Tensor:
     """q ``[Hkv*q_len, G, D]``; k, v ``[rows, D]`` (or ``[rows, 1, D]``); head h owns rows
     ``k_start[h] : k_start[h]+k_len[h]``.  Returns ``[Hkv*q_len, G, D]``."""
     lib = _lib.load()
@@ -253,7 +256,8 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
     need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, int(max_len_k))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
-    rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(), Hkv, G,
+    rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(),
+                             int(k_len_offset), Hkv, G,
                              q_len, D, int(max_len_k), float(scale), 1 if causal else 0, _dtype_code(q.dtype),
                              out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
     check(rc, "kvz_varlen_attn")
