@@ -42,6 +42,14 @@ int kvz_abi_version(void);
 /* thread-local, NUL-terminated description of the last non-zero return */
 const char* kvz_last_error(void);
 
+/* Optional measurement hook (no reference counterpart; the reference times with torch.cuda.synchronize() +
+ * wall clock, utils/func.py:52-79): when enabled, the dominant kernels are bracketed by hipEvents recorded on
+ * the launch stream.  kvz_prof_read synchronises on the recorded events and returns the accumulated time and
+ * launch count of kernel `name` ("score_rowstat", "score_colmax", "compact_gather", "select", "varlen_attn"). */
+void kvz_prof_enable(int on);
+void kvz_prof_reset(void);
+int kvz_prof_read(const char* name, double* total_ms, int64_t* count);
+
 /* ------------------------------------------------------------------------- *
  * a1  KV importance scoring          reference: attention/score.py:36-65
  *     (+ causal mask                 reference: attention/score.py:67-85)
@@ -59,13 +67,19 @@ const char* kvz_last_error(void);
  * ws  : kvz_score_workspace_bytes(...) bytes of device scratch
  * D in {64, 128}.
  * ------------------------------------------------------------------------- */
-size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m);
+size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink);
 int kvz_score_chunk(const void* q, int64_t q_head_stride,
                     const void* k, int64_t k_head_stride, int klen,
                     int sink, int start, int end, int q_len,
                     int Hkv, int G, int D, int dtype,
                     void* out, int64_t out_head_stride,
                     void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+/* Test hook for the rounding chain of a1: out[i] = half( float(in[i]) / float(sqrt(D)) ) computed exactly as the
+ * scoring kernels do (exact-reciprocal multiply when the host's exhaustive search found one, IEEE division
+ * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */
+int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int force_division, void* out_bits,
+                          float* rcp_used, kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102
@@ -79,7 +93,7 @@ int kvz_score_chunk(const void* q, int64_t q_head_stride,
  * scores       : n half values
  * valid_out    : n bytes (0/1), same flat order
  * row_counts   : optional int32[n / row_len]  number of valid entries per row of row_len
- * result_dev   : float[2] on device: {thres, (float)kept_total}; int64 kept at result_dev64[0]
+ * thres_dev    : float[1] on device;  kept_dev: int64[1] on device (number of valid entries)
  * ws           : kvz_select_workspace_bytes() bytes
  * ------------------------------------------------------------------------- */
 size_t kvz_select_workspace_bytes(void);

@@ -12,7 +12,7 @@ import torch  # noqa: F401  MUST precede loading libkvzip_hip.so: torch bundles 
 # must share ONE HIP runtime (streams and device pointers cross the boundary).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkvzip_hip.so")
+LIB_PATH = os.environ.get("KVZIP_HIP_LIB", os.path.join(_HERE, "libkvzip_hip.so"))  # override: A/B builds
 
 KVZ_F16, KVZ_BF16 = 0, 1
 
@@ -21,8 +21,12 @@ _vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_flo
 SIGNATURES = {
     "kvz_abi_version": (_i, []),
     "kvz_last_error": (C.c_char_p, []),
-    "kvz_score_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "kvz_prof_enable": (None, [_i]),
+    "kvz_prof_reset": (None, []),
+    "kvz_prof_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "kvz_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kvz_score_chunk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvz_select_topk_rows": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),

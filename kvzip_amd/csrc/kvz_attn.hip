@@ -187,7 +187,8 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     __syncthreads();
 
     const int64_t pbase = (((int64_t)h * n_rtiles + rt) * n_splits + split) * AT_RT;
-    for (int e = threadIdx.x; e < AT_RT * D; e += AT_THREADS) {
+    const int rows_valid = min(AT_RT, R - rt * AT_RT);
+    for (int e = threadIdx.x; e < rows_valid * D; e += AT_THREADS) {
         const int qq = e / D, d = e % D;
         float mw[AT_WAVES], M = -INFINITY;
 #pragma unroll
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     }
 }
 
-// merge the per-split partials: one block per (head, row tile)
+// merge the per-split partials.  grid = (Hkv, row tiles, D/32); block = 8 split-slices x 32 columns.
+// Every load in the main loop is independent (split-parallel), so the kernel is throughput- not latency-bound.
+constexpr int CB_SLICES = 8;
 template <typename T, int D>
 __global__ __launch_bounds__(AT_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
                                                                         const float* __restrict__ part_ml,
@@ -219,32 +222,72 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_combine_kernel(const f
                                                                         int k_len_offset, int G,
                                                                         int q_len, int chunk, int n_splits,
                                                                         int n_rtiles, T* __restrict__ out) {
-    const int h = blockIdx.x, rt = blockIdx.y;
+    const int h = blockIdx.x, rt = blockIdx.y, dblk = blockIdx.z;
     const int R = q_len * G;
     const int len = k_len[h] + k_len_offset;
     const int nsp = (len + chunk - 1) / chunk;
     const int rows = min(AT_RT, R - rt * AT_RT);
     const int64_t base = ((int64_t)h * n_rtiles + rt) * n_splits * AT_RT;
-    for (int e = threadIdx.x; e < rows * D; e += AT_THREADS) {
-        const int qq = e / D, d = e % D;
-        float M = -INFINITY;
-        for (int s = 0; s < nsp; ++s) M = fmaxf(M, part_ml[(base + (int64_t)s * AT_RT + qq) * 2]);
-        float acc = 0.f, lsum = 0.f;
-        for (int s = 0; s < nsp; ++s) {
-            const int64_t pi = base + (int64_t)s * AT_RT + qq;
-            const float ms = part_ml[pi * 2];
-            const float wgt = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
-            acc += wgt * part_o[pi * D + d];
-            lsum += wgt * part_ml[pi * 2 + 1];
+    const int tid = threadIdx.x;
+    const int dl = tid & 31, slice = tid >> 5;
+
+    __shared__ float s_max[AT_RT][AT_RT + 1];
+    __shared__ float s_M[AT_RT];
+    __shared__ float s_acc[CB_SLICES][AT_RT][33];
+    __shared__ float s_l[CB_SLICES][AT_RT];
+
+    // global maximum per query row
+    {
+        const int qq = tid & 15, grp = tid >> 4;  // 16 groups stride over the splits
+        float mx = -INFINITY;
+        for (int s = grp; s < nsp; s += 16) mx = fmaxf(mx, part_ml[(base + (int64_t)s * AT_RT + qq) * 2]);
+        s_max[grp][qq] = mx;
+    }
+    __syncthreads();
+    if (tid < AT_RT) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) mx = fmaxf(mx, s_max[g2][tid]);
+        s_M[tid] = mx;
+    }
+    __syncthreads();
+
+    float acc[AT_RT];
+    float lacc[AT_RT];
+#pragma unroll
+    for (int qq = 0; qq < AT_RT; ++qq) { acc[qq] = 0.f; lacc[qq] = 0.f; }
+    const int d = dblk * 32 + dl;
+    for (int s = slice; s < nsp; s += CB_SLICES) {
+        const int64_t pi = base + (int64_t)s * AT_RT;
+#pragma unroll
+        for (int qq = 0; qq < AT_RT; ++qq) {
+            if (qq < rows) {
+                const float2 ml = *reinterpret_cast<const float2*>(part_ml + (pi + qq) * 2);
+                const float wgt = (ml.x == -INFINITY) ? 0.f : exp2f(ml.x - s_M[qq]);
+                acc[qq] += wgt * part_o[(pi + qq) * D + d];
+                lacc[qq] += wgt * ml.y;
+            }
         }
-        const float r = (lsum > 0.f) ? acc / lsum : 0.f;
-        out[((int64_t)h * R + rt * AT_RT + qq) * D + d] = (T)r;
+    }
+#pragma unroll
+    for (int qq = 0; qq < AT_RT; ++qq) {
+        s_acc[slice][qq][dl] = acc[qq];
+        if (dl == 0) s_l[slice][qq] = lacc[qq];
+    }
+    __syncthreads();
+    for (int e = tid; e < rows * 32; e += AT_THREADS) {
+        const int qq = e >> 5, dd = e & 31;
+        float a = 0.f, l = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < CB_SLICES; ++sl) { a += s_acc[sl][qq][dd]; l += s_l[sl][qq]; }
+        const float r = (l > 0.f) ? a / l : 0.f;
+        out[((int64_t)h * R + rt * AT_RT + qq) * D + dblk * 32 + dd] = (T)r;
     }
 }
 
 static inline int attn_chunk(int Hkv, int max_len_k) {
-    // aim for ~2048 (head, chunk) work items; chunk is a multiple of one block-iteration (128 keys)
-    int64_t c = ((int64_t)Hkv * max_len_k + 2047) / 2048;
+    // aim for ~768 (head, chunk) work items (3 blocks per CU); chunk is a multiple of one block-iteration (128 keys)
+    int64_t c = ((int64_t)Hkv * max_len_k + 767) / 768;
     c = (c + 127) / 128 * 128;
     if (c < 128) c = 128;
     return (int)c;
@@ -259,11 +302,12 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
     float* part_o = reinterpret_cast<float*>(ws);
     float* part_ml = part_o + (size_t)Hkv * n_rtiles * n_splits * AT_RT * D;
+    ProfScope ps("varlen_attn", stream);  // split + combine
     hipLaunchKernelGGL((varlen_attn_split_kernel<T, D>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
                        reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
                        k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
     KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
-    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles), dim3(AT_THREADS), 0, stream, part_o,
+    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles, D / 32), dim3(AT_THREADS), 0, stream, part_o,
                        part_ml, k_len, k_len_offset, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
     KVZ_CHECK_LAUNCH("varlen_attn_combine_kernel");
     return KVZ_OK;

@@ -31,6 +31,22 @@ void set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// ---- optional per-kernel profiler (kvz_prof_enable): hipEvents on the launch stream ------------------
+bool prof_enabled();
+void prof_begin(const char* name, hipStream_t stream, int* slot, size_t* idx);
+void prof_end(hipStream_t stream, int slot, size_t idx);
+struct ProfScope {
+    hipStream_t stream;
+    int slot = -1;
+    size_t idx = 0;
+    ProfScope(const char* name, hipStream_t s) : stream(s) {
+        if (prof_enabled()) prof_begin(name, s, &slot, &idx);
+    }
+    ~ProfScope() {
+        if (slot >= 0) prof_end(stream, slot, idx);
+    }
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- half / bf16 bit helpers ------------------------------------------------------------

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void append_inplace_kernel(char* __restrict__ 
 static int launch_gather(const CompactArgs& a, int layers, hipStream_t stream) {
     dim3 grid((unsigned)a.ntiles, (unsigned)a.Hkv, (unsigned)layers);
     dim3 block(CP_THREADS);
+    ProfScope ps("compact_gather", stream);
     switch (a.row_bytes / 16) {
         case 4: hipLaunchKernelGGL(compact_gather_kernel<4>, grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL(compact_gather_kernel<8>, grid, block, 0, stream, a); break;

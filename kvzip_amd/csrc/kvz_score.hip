@@ -18,6 +18,11 @@
 // reads are bank-conflict free.  Bound: MFMA co-limited by the VALU rounding chain.
 #include "kvz_common.h"
 
+#include <math.h>
+#include <string.h>
+
+#include <type_traits>
+
 namespace kvz {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -35,45 +40,48 @@ template <> struct Mfma32<__bf16> {
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int SC_THREADS = 256;
-constexpr int SC_TILE = 128;   // streamed rows per LDS tile
-constexpr int SC_COLS = 128;   // stationary columns per block (32 per wave)
+constexpr int SC_THREADS = 512;  // 8 waves share one streamed tile; 2 blocks per CU -> 4 waves per SIMD (<= 128 VGPRs)
+constexpr int SC_WAVES = SC_THREADS / 64;
+constexpr int SC_TILE = 128;     // streamed rows per LDS tile
+constexpr int SC_COLS = SC_WAVES * 32;  // stationary columns per block (32 per wave)
+constexpr int SC_KSPLIT_TILES = 8;  // pass A: key tiles per block (load balance under the causal mask)
 
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
     const void* k;       // [Hkv, klen, D]
     int64_t q_head_stride, k_head_stride;  // elements
     int klen, sink, start, m, q_len, G;
-    float2* stats;       // [Hkv, G*q_len]  (m_r, log l_r)
-    int32_t* colmax;     // [Hkv, m]  order-encoded float
+    float2* stats;       // [key_splits, Hkv, G*q_len]  partial (m_r, l'_r) of each key slice (l' relative to fl(m*log2e))
+    int key_splits;      // pass A: slices of SC_KSPLIT_TILES key tiles
+    float* colpart;      // [row_splits, Hkv, m]  per-slice column maxima of the log-softmax
     void* out;           // [Hkv, m] half
     int64_t out_head_stride;
     int row_splits;      // pass B
-    float inv_c, c;      // float(sqrt(D)) and its reciprocal
+    float c;             // float32(sqrt(D))
+    float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
+#ifdef KVZ_TRACE
+    unsigned long long* trace;  // debug build only: per-block timestamps
+#endif
 };
 
-// reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half
-template <typename T>
-__device__ static inline float round_chain(float acc, float c) {
+// reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
+// The division is an IEEE fp32 division whose result is immediately rounded to 16 bits.  Because the dividend is a
+// 16-bit value there are only 65536 cases, and the host verifies exhaustively (find_exact_reciprocal) that one
+// fp32 multiply by `rcp` gives the identical 16-bit result for all of them; if no such constant exists the kernel
+// falls back to the true division.
+template <typename T, bool FAST>
+__device__ static inline float round_chain(float acc, float c, float rcp) {
     const T h1 = (T)acc;
-    const float d = (float)h1 / c;  // IEEE fp32 division (no fast-math)
+    const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
     const T h2 = (T)d;
     return (float)h2;
 }
-
-// order-preserving float <-> int encoding for atomicMax
-__device__ static inline int32_t f2ord(float f) {
-    int32_t i = __float_as_int(f);
-    return i >= 0 ? i : i ^ 0x7FFFFFFF;
-}
-__device__ static inline float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
 template <int D> struct ScoreCfg {
     static constexpr int ROW_BYTES = D * 2;
     static constexpr int CPR = ROW_BYTES / 16;                       // 16-byte chunks per row
     static constexpr int KK = D / 16;                                // MFMA k-steps
     static constexpr int TILE_BYTES = SC_TILE * ROW_BYTES;
-    static constexpr int LOADS = SC_TILE * CPR / SC_THREADS;         // 16-byte loads per thread per tile
     // swizzled byte offset of 16-byte chunk `chunk` of tile row `row`
     __device__ static inline int lds_off(int row, int chunk) {
         if (D == 128) return row * ROW_BYTES + ((chunk ^ (row & 15)) << 4);
@@ -81,61 +89,71 @@ template <int D> struct ScoreCfg {
     }
 };
 
-// ---- staging: one 128-row tile, global -> registers -> swizzled LDS --------------------------------
+// ---- staging: one 128-row tile, HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR round trip) ---------
+// One wave-instruction writes 1 KiB = 64 lanes x 16 B LINEARLY (wave-uniform base + lane*16).  The XOR swizzle of
+// the tile is therefore applied on the SOURCE side: LDS position p of a row receives global chunk p ^ f(row), and
+// fragment reads use lds_off(row, chunk) = position chunk ^ f(row) (same involution on both sides).
+// rowptr clamps out-of-range rows to a valid row: loads are UNCONDITIONAL; out-of-range rows are neutralised
+// downstream (causal limit in pass A, m = +inf statistics in pass B).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 template <int D, typename RowPtr>
-__device__ static inline void stage_load(u32x4 (&regs)[ScoreCfg<D>::LOADS], int row0, RowPtr rowptr) {
+__device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int wave, int lane) {
     typedef ScoreCfg<D> C;
+    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;  // 4 (D = 128) or 8 (D = 64)
+    constexpr int INSTR = C::TILE_BYTES / 1024;
+    constexpr int PER_WAVE = INSTR / SC_WAVES;
+    static_assert(PER_WAVE >= 1 && INSTR % SC_WAVES == 0, "tile / wave layout");
 #pragma unroll
-    for (int it = 0; it < C::LOADS; ++it) {
-        const int c = it * SC_THREADS + threadIdx.x;
-        const int row = c / C::CPR, chunk = c % C::CPR;
-        const char* p = rowptr(row0 + row);
-        regs[it] = p ? *reinterpret_cast<const u32x4*>(p + chunk * 16) : u32x4{0, 0, 0, 0};
-    }
-}
-template <int D>
-__device__ static inline void stage_store(const u32x4 (&regs)[ScoreCfg<D>::LOADS], char* buf) {
-    typedef ScoreCfg<D> C;
-#pragma unroll
-    for (int it = 0; it < C::LOADS; ++it) {
-        const int c = it * SC_THREADS + threadIdx.x;
-        const int row = c / C::CPR, chunk = c % C::CPR;
-        *reinterpret_cast<u32x4*>(buf + C::lds_off(row, chunk)) = regs[it];
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int ci = i * SC_WAVES + wave;  // wave-uniform 1-KiB piece of the tile
+        const int row = ci * ROWS_PER_INSTR + lane / C::CPR;
+        const int p = lane % C::CPR;
+        const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
+        const char* src = rowptr(row0 + row) + chunk * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ci * 1024), 16, 0, 0);
     }
 }
 
 // ---- pass A: per-query-row softmax statistics ------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(SC_THREADS, 2) void score_rowstat_kernel(ScoreArgs a) {
+// Online softmax in the exp2 domain: the running pseudo-maximum ml2 = fl(m * log2e) is an fp32 number, every term
+// is exp2(fma(x, log2e, -ml2)) (one rounding), and the common factor 2^(m*log2e - ml2) that this introduces
+// into l is removed exactly at the end (delta = fma(m, log2e, -ml2)).
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs a) {
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES];
+    constexpr float L2E = 1.44269504088896340736f;
 
     const int h = blockIdx.y;
     const int R = a.G * a.q_len;
     const int KT = a.sink + a.m + a.q_len;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+#ifdef KVZ_TRACE
+    unsigned long long tr0 = wall_clock64(), tr1 = 0, tr2 = 0;
+#endif
 
     // stationary operand: 32 query rows per wave, one per lane (B operand: col = row index)
     const int r = blockIdx.x * SC_COLS + wave * 32 + l31;
     const bool rvalid = r < R;
-    const int g = rvalid ? r / a.q_len : 0;
-    const int qi = rvalid ? r - g * a.q_len : 0;
+    const int rc = min(r, R - 1);  // out-of-range lanes shadow the last row; their result is never stored
+    const int g = rc / a.q_len;
+    const int qi = rc - g * a.q_len;
     v8 bq[C::KK];
     {
         const char* qp = reinterpret_cast<const char*>(a.q) +
                          (((int64_t)h * a.G + g) * a.q_head_stride + (int64_t)qi * D) * 2 + half * 16;
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
-            u32x4 raw = rvalid ? *reinterpret_cast<const u32x4*>(qp + kk * 32) : u32x4{0, 0, 0, 0};
-            bq[kk] = __builtin_bit_cast(v8, raw);
-        }
+        for (int kk = 0; kk < C::KK; ++kk)
+            bq[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(qp + kk * 32));
     }
     // key j (virtual index) is visible to query i iff j <= sink + m + i  (reference score.py:67-85)
-    const int limit = rvalid ? a.sink + a.m + qi : -1;
+    const int limit = a.sink + a.m + qi;
 
-    // block-uniform loop bound: the largest limit of any row in the block
+    // block-uniform loop bound: the largest limit of any row in the block; this block owns key tiles [t_lo, t_hi)
     int kend;
     {
         const int r0 = blockIdx.x * SC_COLS;
@@ -144,29 +162,24 @@ __global__ __launch_bounds__(SC_THREADS, 2) void score_rowstat_kernel(ScoreArgs 
         kend = min(KT, a.sink + a.m + qmax + 1);
     }
     const int ntiles = (kend + SC_TILE - 1) / SC_TILE;
+    const int t_lo = blockIdx.z * SC_KSPLIT_TILES;
+    const int t_hi = min(ntiles, t_lo + SC_KSPLIT_TILES);
 
     const char* kh = reinterpret_cast<const char*>(a.k) + (int64_t)h * a.k_head_stride * 2;
+    const int off_ctx = a.start - a.sink;                       // virtual -> cache row, ctx segment
+    const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
     auto keyptr = [&](int kv) -> const char* {
-        if (kv >= KT) return nullptr;
-        int row;
-        if (kv < a.sink) row = kv;
-        else if (kv < a.sink + a.m) row = a.start + (kv - a.sink);
-        else row = a.klen - a.q_len + (kv - a.sink - a.m);
+        kv = min(kv, KT - 1);
+        const int row = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
         return kh + (int64_t)row * C::ROW_BYTES;
     };
 
-    u32x4 st[C::LOADS];
-    stage_load<D>(st, 0, keyptr);
-    stage_store<D>(st, lds);
-    __syncthreads();
-
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, ml2_run = 0.f, l_run = 0.f;
     const int diag0 = a.sink + a.m;  // first key that can be masked for some row
 
-    for (int t = 0; t < ntiles; ++t) {
-        const char* buf = lds + (t & 1) * C::TILE_BYTES;
-        if (t + 1 < ntiles) stage_load<D>(st, (t + 1) * SC_TILE, keyptr);
-        const bool need_mask = (t * SC_TILE + SC_TILE - 1) > diag0;  // also covers kv >= KT
+    // one 128-key tile = 4 blocks of 32 keys; MASK = tile straddles / lies beyond the causal diagonal
+    auto tile_body = [&](const char* buf, int t, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
         for (int kb = 0; kb < SC_TILE / 32; ++kb) {
             f16v acc;
@@ -179,39 +192,90 @@ __global__ __launch_bounds__(SC_THREADS, 2) void score_rowstat_kernel(ScoreArgs 
             }
             float x[16];
             float tmax = -INFINITY;
+            const int rel = limit - (t * SC_TILE + kb * 32 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float v = round_chain<T>(acc[i], a.c);
-                if (need_mask) {
-                    const int kv = t * SC_TILE + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    v = (kv <= limit) ? v : -INFINITY;
-                }
+                float v = round_chain<T, FAST>(acc[i], a.c, a.rcp);
+                if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : -INFINITY;
                 x[i] = v;
                 tmax = fmaxf(tmax, v);
             }
-            const float m_new = fmaxf(m_run, tmax);
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            float psum = 0.f;
+            if (tmax > m_run) {  // new running maximum: rescale the partial sum
+                const float ml2_new = tmax * L2E;
+                l_run *= __builtin_amdgcn_exp2f(ml2_run - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
+                m_run = tmax;
+                ml2_run = ml2_new;
+            }
+            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) psum += __expf(x[i] - m_safe);
-            l_run = l_run * __expf(m_run - m_safe) + psum;
-            m_run = m_new;
+            for (int i = 0; i < 16; i += 2) {
+                ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], L2E, -ml2_run));
+                ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[i + 1], L2E, -ml2_run));
+            }
+            l_run += ps0 + ps1;  // (all-masked so far: x = -inf -> exp2(-inf) = 0)
         }
-        if (t + 1 < ntiles) stage_store<D>(st, lds + ((t + 1) & 1) * C::TILE_BYTES);
+    };
+
+    if (t_lo < t_hi) {
+        stage_tile<D>(lds, t_lo * SC_TILE, keyptr, wave, lane);
         __syncthreads();
+#ifdef KVZ_TRACE
+        tr1 = wall_clock64();
+#endif
+        for (int t = t_lo; t < t_hi; ++t) {
+            const int cur = (t - t_lo) & 1;
+            const char* buf = lds + cur * C::TILE_BYTES;
+            if (t + 1 < t_hi) stage_tile<D>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, keyptr, wave, lane);
+            if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(buf, t, std::true_type{});   // also covers kv >= KT
+            else tile_body(buf, t, std::false_type{});
+            __syncthreads();  // next tile landed (vmcnt drained) and everybody is done reading this one
+        }
     }
+#ifdef KVZ_TRACE
+    tr2 = wall_clock64();
+    if (threadIdx.x == 0 && a.trace) {
+        const int64_t b = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[b * 6 + 0] = tr0; a.trace[b * 6 + 1] = tr1; a.trace[b * 6 + 2] = tr2;
+        a.trace[b * 6 + 3] = wall_clock64(); a.trace[b * 6 + 4] = ((unsigned long long)xcc << 32) | hwid;
+        a.trace[b * 6 + 5] = (unsigned long long)(t_hi > t_lo ? t_hi - t_lo : 0);
+    }
+#endif
     // merge the two half-waves (they saw disjoint keys of the same query row)
     const float m_o = __shfl_xor(m_run, 32, 64);
+    const float ml2_o = __shfl_xor(ml2_run, 32, 64);
     const float l_o = __shfl_xor(l_run, 32, 64);
     const float M = fmaxf(m_run, m_o);
-    const float Ms = (M == -INFINITY) ? 0.f : M;
-    const float L = l_run * __expf(m_run - Ms) + l_o * __expf(m_o - Ms);
-    if (half == 0 && rvalid) a.stats[(int64_t)h * R + r] = make_float2(M, logf(L));
+    const float ML2 = (m_run >= m_o) ? ml2_run : ml2_o;
+    const float Lp = l_run * __builtin_amdgcn_exp2f(ml2_run - ML2) + l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
+    // partial statistics of this key slice (empty slice: m = -inf, l' = 0)
+    if (half == 0 && rvalid) a.stats[((int64_t)blockIdx.z * gridDim.y + h) * R + r] = make_float2(M, Lp);
+}
+
+// merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
+// 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).
+__global__ void score_merge_stats_kernel(float2* __restrict__ stats, int key_splits, int64_t rows_total) {
+    constexpr float L2E = 1.44269504088896340736f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_total) return;
+    float M = -INFINITY;
+    for (int s = 0; s < key_splits; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
+    const float ML2 = M * L2E;
+    float Lp = 0.f;
+    for (int s = 0; s < key_splits; ++s) {
+        const float2 ps = stats[s * rows_total + i];
+        Lp += ps.y * __builtin_amdgcn_exp2f(ps.x * L2E - ML2);
+    }
+    const float delta = __builtin_fmaf(M, L2E, -ML2);
+    stats[i] = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
 
 // ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(SC_THREADS, 2) void score_colmax_kernel(ScoreArgs a) {
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(SC_THREADS, 4) void score_colmax_kernel(ScoreArgs a) {
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
@@ -219,7 +283,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void score_colmax_kernel(ScoreArgs a
 
     const int h = blockIdx.z;
     const int R = a.G * a.q_len;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
     // stationary operand: 32 ctx keys per wave (B operand)
@@ -230,122 +295,228 @@ __global__ __launch_bounds__(SC_THREADS, 2) void score_colmax_kernel(ScoreArgs a
         const char* kp = reinterpret_cast<const char*>(a.k) +
                          ((int64_t)h * a.k_head_stride + (int64_t)(a.start + (jvalid ? j : 0)) * D) * 2 + half * 16;
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
-            u32x4 raw = jvalid ? *reinterpret_cast<const u32x4*>(kp + kk * 32) : u32x4{0, 0, 0, 0};
-            bk[kk] = __builtin_bit_cast(v8, raw);
-        }
+        for (int kk = 0; kk < C::KK; ++kk)
+            bk[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
     }
-    // this block's slice of the query rows (tiles of 128)
+    // this block's slice of the query rows (tiles of 128); the host picks row_splits so that no slice is empty
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
     const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
     const int t_begin = blockIdx.y * per;
     const int t_end = min(total_tiles, t_begin + per);
-    if (t_begin >= t_end) return;
 
     const char* qbase = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * a.q_head_stride * 2;
     auto rowptr = [&](int r) -> const char* {
-        if (r >= R) return nullptr;
+        r = min(r, R - 1);
         const int g = r / a.q_len;
         const int qi = r - g * a.q_len;
         return qbase + ((int64_t)g * a.q_head_stride + (int64_t)qi * D) * 2;
     };
-    const float2* stats_h = a.stats + (int64_t)h * R;
+    const float2* stats_h = a.stats + (int64_t)h * R;  // merged (m_r, log l_r)
     auto load_stat = [&](int t) -> float2 {
-        const int r = t * SC_TILE + (int)threadIdx.x;
+        const int r = t * SC_TILE + (int)(threadIdx.x & (SC_TILE - 1));
+        const float2 v = stats_h[min(r, R - 1)];
         // rows beyond R get (m = +inf): x - inf = -inf never wins the max
-        return (threadIdx.x < SC_TILE) ? ((r < R) ? stats_h[r] : make_float2(INFINITY, 0.f)) : make_float2(0.f, 0.f);
+        return (r < R) ? v : make_float2(INFINITY, 0.f);
     };
 
-    u32x4 st[C::LOADS];
-    stage_load<D>(st, t_begin * SC_TILE, rowptr);
-    float2 sst = load_stat(t_begin);
-    stage_store<D>(st, lds);
-    if (threadIdx.x < SC_TILE) lstat[threadIdx.x] = sst;
-    __syncthreads();
-
     float best = -INFINITY;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
-        const char* buf = lds + cur * C::TILE_BYTES;
-        const float2* ls = lstat + cur * SC_TILE;
-        if (t + 1 < t_end) {
-            stage_load<D>(st, (t + 1) * SC_TILE, rowptr);
-            sst = load_stat(t + 1);
-        }
-#pragma unroll 1
-        for (int kb = 0; kb < SC_TILE / 32; ++kb) {
-            f16v acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
-                acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, raw), bk[kk], acc);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float2 s = ls[kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half];
-                const float v = round_chain<T>(acc[i], a.c);
-                best = fmaxf(best, (v - s.x) - s.y);
-            }
-        }
-        if (t + 1 < t_end) {
-            stage_store<D>(st, lds + (cur ^ 1) * C::TILE_BYTES);
-            if (threadIdx.x < SC_TILE) lstat[(cur ^ 1) * SC_TILE + threadIdx.x] = sst;
-        }
+    if (t_begin < t_end) {
+        stage_tile<D>(lds, t_begin * SC_TILE, rowptr, wave, lane);
+        float2 sst = load_stat(t_begin);
+        if (threadIdx.x < SC_TILE) lstat[threadIdx.x] = sst;
         __syncthreads();
+
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            const char* buf = lds + cur * C::TILE_BYTES;
+            const float2* ls = lstat + cur * SC_TILE;
+            if (t + 1 < t_end) {
+                stage_tile<D>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, rowptr, wave, lane);
+                sst = load_stat(t + 1);
+            }
+#pragma unroll 1
+            for (int kb = 0; kb < SC_TILE / 32; ++kb) {
+                f16v acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < C::KK; ++kk) {
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
+                    acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, raw), bk[kk], acc);
+                }
+                float b0 = -INFINITY, b1 = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const int rr = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    const float2 s0 = ls[rr], s1 = ls[rr + 1];
+                    b0 = fmaxf(b0, (round_chain<T, FAST>(acc[i], a.c, a.rcp) - s0.x) - s0.y);
+                    b1 = fmaxf(b1, (round_chain<T, FAST>(acc[i + 1], a.c, a.rcp) - s1.x) - s1.y);
+                }
+                best = fmaxf(best, fmaxf(b0, b1));
+            }
+            if (t + 1 < t_end && threadIdx.x < SC_TILE) lstat[(cur ^ 1) * SC_TILE + threadIdx.x] = sst;
+            __syncthreads();
+        }
     }
     best = fmaxf(best, __shfl_xor(best, 32, 64));
-    if (half == 0 && jvalid) atomicMax(&a.colmax[(int64_t)h * a.m + j], f2ord(best));
-}
-
-__global__ void score_init_kernel(int32_t* colmax, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) colmax[i] = f2ord(-INFINITY);
+    if (half == 0 && jvalid) a.colpart[((int64_t)blockIdx.y * gridDim.z + h) * a.m + j] = best;
 }
 
 template <typename T>
-__global__ void score_finalize_kernel(const int32_t* __restrict__ colmax, int m, T* __restrict__ out,
+__global__ void score_finalize_kernel(const float* __restrict__ colpart, int splits, int Hkv, int m, T* __restrict__ out,
                                       int64_t out_head_stride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (j >= m) return;
-    const float t = ord2f(colmax[(int64_t)h * m + j]);
+    float t = -INFINITY;
+    for (int s = 0; s < splits; ++s) t = fmaxf(t, colpart[((int64_t)s * Hkv + h) * m + j]);
     out[(int64_t)h * out_head_stride + j] = (T)expf(t);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <typename T, int D>
-static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream) {
-    const int R = a.G * a.q_len;
-    const int64_t ncol = (int64_t)Hkv * a.m;
-    hipLaunchKernelGGL(score_init_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, a.colmax, ncol);
-    KVZ_CHECK_LAUNCH("score_init_kernel");
-    hipLaunchKernelGGL((score_rowstat_kernel<T, D>), dim3((R + SC_COLS - 1) / SC_COLS, Hkv), dim3(SC_THREADS), 0, stream, a);
-    KVZ_CHECK_LAUNCH("score_rowstat_kernel");
-    const int ctiles = (a.m + SC_COLS - 1) / SC_COLS;
-    const int rtiles = (R + SC_TILE - 1) / SC_TILE;
-    // enough blocks to fill 256 CUs twice over
-    int splits = (1024 + ctiles * Hkv - 1) / (ctiles * Hkv);
+// key slices of pass A
+static inline int score_key_splits(int sink, int m, int q_len) {
+    const int ntiles = (sink + m + q_len + SC_TILE - 1) / SC_TILE;
+    return (ntiles + SC_KSPLIT_TILES - 1) / SC_KSPLIT_TILES;
+}
+// number of row slices of pass B: enough blocks to fill 256 CUs about twice, no empty slice
+static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
+    const int ctiles = (m + SC_COLS - 1) / SC_COLS;
+    const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
+    int splits = (768 + ctiles * Hkv - 1) / (ctiles * Hkv);
     if (splits > rtiles) splits = rtiles;
     if (splits < 1) splits = 1;
-    a.row_splits = splits;
-    hipLaunchKernelGGL((score_colmax_kernel<T, D>), dim3(ctiles, splits, Hkv), dim3(SC_THREADS), 0, stream, a);
+    const int per = (rtiles + splits - 1) / splits;
+    return (rtiles + per - 1) / per;
+}
+
+// ---- host: exhaustive search for an exact reciprocal constant ----------------------------------------------
+static inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t ex = (u >> 23) & 0xFFu;
+    uint32_t man = u & 0x7FFFFFu;
+    if (ex == 0xFF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+    const int e = (int)ex - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;  // 14..24
+        uint32_t r = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;  // may carry into the exponent (correct)
+    return (uint16_t)(sign | r);
+}
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0));
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, ex = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu, u;
+    if (ex == 0) {
+        if (!man) u = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            u = sign | ((uint32_t)(112 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (ex == 31) u = sign | 0x7F800000u | (man << 13);
+    else u = sign | ((ex + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// returns r with  half(x * r) == half(x / c)  for every finite 16-bit x (zero sign included), or 0 if none of the
+// neighbours of 1/c qualifies.
+static float find_exact_reciprocal(float c, int dtype) {
+    static float cache[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [dtype][{c, r, valid}]
+    if (cache[dtype][2] != 0.f && cache[dtype][0] == c) return cache[dtype][1];
+    const float base = 1.0f / c;
+    float cand[5] = {base, nextafterf(base, 1.f), nextafterf(base, 0.f), 0.f, 0.f};
+    cand[3] = nextafterf(cand[1], 1.f);
+    cand[4] = nextafterf(cand[2], 0.f);
+    float found = 0.f;
+    for (int ci = 0; ci < 5 && found == 0.f; ++ci) {
+        bool ok = true;
+        for (uint32_t b = 0; b < 65536 && ok; ++b) {
+            float x;
+            if (dtype == KVZ_BF16) {
+                const uint32_t u = b << 16;
+                memcpy(&x, &u, 4);
+            } else x = f16_bits_to_f32((uint16_t)b);
+            if (!(x - x == 0.f)) continue;  // inf / nan
+            volatile float dq = x / c, mq = x * cand[ci];
+            const uint16_t a16 = dtype == KVZ_BF16 ? f32_to_bf16_rne(dq) : f32_to_f16_rne(dq);
+            const uint16_t b16 = dtype == KVZ_BF16 ? f32_to_bf16_rne(mq) : f32_to_f16_rne(mq);
+            ok = (a16 == b16);
+        }
+        if (ok) found = cand[ci];
+    }
+    cache[dtype][0] = c; cache[dtype][1] = found; cache[dtype][2] = 1.f;
+    return found;
+}
+
+template <typename T, int D, bool FAST>
+static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
+    const int R = a.G * a.q_len;
+    {
+        ProfScope ps("score_rowstat", stream);
+        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3((R + SC_COLS - 1) / SC_COLS, Hkv, a.key_splits),
+                           dim3(SC_THREADS), 0, stream, a);
+    }
+    KVZ_CHECK_LAUNCH("score_rowstat_kernel");
+    {
+        const int64_t rows_total = (int64_t)Hkv * R;
+        hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a.stats,
+                           a.key_splits, rows_total);
+    }
+    KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
+    const int ctiles = (a.m + SC_COLS - 1) / SC_COLS;
+    a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
+    {
+        ProfScope ps("score_colmax", stream);
+        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles, a.row_splits, Hkv), dim3(SC_THREADS), 0, stream, a);
+    }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
-    hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colmax, a.m,
-                       reinterpret_cast<T*>(a.out), a.out_head_stride);
+    hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
+                       a.row_splits, Hkv, a.m, reinterpret_cast<T*>(a.out), a.out_head_stride);
     KVZ_CHECK_LAUNCH("score_finalize_kernel");
     return KVZ_OK;
+}
+template <typename T, int D>
+static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream) {
+    return a.rcp != 0.f ? launch_score_impl<T, D, true>(a, Hkv, stream) : launch_score_impl<T, D, false>(a, Hkv, stream);
 }
 
 }  // namespace kvz
 
 using namespace kvz;
 
-extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m) {
-    if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0) return 0;
-    return align256((size_t)Hkv * G * q_len * sizeof(float2)) + align256((size_t)Hkv * m * sizeof(int32_t));
+#ifdef KVZ_TRACE
+static unsigned long long* g_trace = nullptr;
+extern "C" void kvz_debug_set_trace(void* p) { g_trace = (unsigned long long*)p; }
+#endif
+
+static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
+    return align256((size_t)score_key_splits(sink, m, q_len) * Hkv * G * q_len * sizeof(float2));
+}
+
+extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
+    if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0 || sink < 0) return 0;
+    return score_stats_bytes(Hkv, G, q_len, m, sink) +
+           align256((size_t)score_row_splits(Hkv, G, q_len, m) * Hkv * m * sizeof(float));
 }
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -362,20 +533,61 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     KVZ_REQUIRE(aligned16(q) && aligned16(k), KVZ_EINVAL, "kvz_score_chunk: q/k must be 16-byte aligned");
     KVZ_REQUIRE((q_head_stride * 2) % 16 == 0 && (k_head_stride * 2) % 16 == 0, KVZ_EINVAL,
                 "kvz_score_chunk: head strides must be multiples of 8 elements");
-    KVZ_REQUIRE(ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m), KVZ_EWORKSPACE,
+    KVZ_REQUIRE(ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink), KVZ_EWORKSPACE,
                 "kvz_score_chunk: workspace too small");
     ScoreArgs a{};
     a.q = q; a.k = k; a.q_head_stride = q_head_stride; a.k_head_stride = k_head_stride;
     a.klen = klen; a.sink = sink; a.start = start; a.m = m; a.q_len = q_len; a.G = G;
     a.stats = reinterpret_cast<float2*>(ws);
-    a.colmax = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + align256((size_t)Hkv * G * q_len * sizeof(float2)));
+    a.key_splits = score_key_splits(sink, m, q_len);
+    a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
-    a.c = sqrtf((float)D);  // float32(math.sqrt(D)): sqrt of 64/128 rounds identically in float and double->float
-    a.inv_c = 1.0f / a.c;
+#ifdef KVZ_TRACE
+    a.trace = g_trace;
+#endif
+    a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
+    a.rcp = find_exact_reciprocal(a.c, dtype);
     if (dtype == KVZ_F16) {
         if (D == 128) return launch_score<_Float16, 128>(a, Hkv, stream);
         return launch_score<_Float16, 64>(a, Hkv, stream);
     }
     if (D == 128) return launch_score<__bf16, 128>(a, Hkv, stream);
     return launch_score<__bf16, 64>(a, Hkv, stream);
+}
+
+// test hook: the rounding chain on raw 16-bit patterns (exhaustive-check of the exact-reciprocal path on the device)
+namespace kvz {
+template <typename T, bool FAST>
+__global__ void chain_probe_kernel(const uint16_t* in, int n, float c, float rcp, uint16_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T x;
+    uint16_t b = in[i];
+    __builtin_memcpy(&x, &b, 2);
+    // acc = float(x) is exactly representable, so half(acc) == x: the probe isolates the division step
+    const float r = round_chain<T, FAST>((float)x, c, rcp);
+    const T h = (T)r;
+    __builtin_memcpy(&b, &h, 2);
+    out[i] = b;
+}
+}  // namespace kvz
+extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int force_division, void* out_bits,
+                                     float* rcp_used, kvz_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(in_bits && out_bits && n > 0, KVZ_EINVAL, "kvz_debug_round_chain: bad arguments");
+    const float c = sqrtf((float)D);
+    const float rcp = force_division ? 0.f : find_exact_reciprocal(c, dtype);
+    if (rcp_used) *rcp_used = rcp;
+    dim3 grid((n + 255) / 256), block(256);
+    const uint16_t* in = reinterpret_cast<const uint16_t*>(in_bits);
+    uint16_t* out = reinterpret_cast<uint16_t*>(out_bits);
+    if (dtype == KVZ_F16) {
+        if (rcp != 0.f) hipLaunchKernelGGL((chain_probe_kernel<_Float16, true>), grid, block, 0, stream, in, n, c, rcp, out);
+        else hipLaunchKernelGGL((chain_probe_kernel<_Float16, false>), grid, block, 0, stream, in, n, c, rcp, out);
+    } else {
+        if (rcp != 0.f) hipLaunchKernelGGL((chain_probe_kernel<__bf16, true>), grid, block, 0, stream, in, n, c, rcp, out);
+        else hipLaunchKernelGGL((chain_probe_kernel<__bf16, false>), grid, block, 0, stream, in, n, c, rcp, out);
+    }
+    KVZ_CHECK_LAUNCH("chain_probe_kernel");
+    return KVZ_OK;
 }

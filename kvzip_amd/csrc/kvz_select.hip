@@ -388,6 +388,7 @@ extern "C" int kvz_select_threshold(const void* scores, int64_t n, double ratio,
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     const uint16_t* s16 = reinterpret_cast<const uint16_t*>(scores);
+    ProfScope ps("select", stream);  // the three streaming passes
     hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, hist_hi);
     KVZ_CHECK_LAUNCH("select_hist_hi_kernel");
     hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, (uint64_t)idx,

@@ -89,6 +89,15 @@ class _CacheBase(KVScore):
         self.key_cache[layer_idx] = self._store_k[layer_idx][:, :, :f + t]
         self.value_cache[layer_idx] = self._store_v[layer_idx][:, :, :f + t]
 
+    def adopt_dense(self, store_k: List[torch.Tensor], store_v: List[torch.Tensor], filled: int):
+        """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
+        serving engine prefilled elsewhere); ``filled`` rows are in use."""
+        self._store_k, self._store_v = list(store_k), list(store_v)
+        self._fill = [filled for _ in store_k]
+        self.key_cache = [k[:, :, :filled] for k in self._store_k]
+        self.value_cache = [v[:, :, :filled] for v in self._store_v]
+        self._seen_tokens = filled
+
     def _dense_slice(self, seen_token_prev: int):
         for l in range(len(self._store_k)):
             self._fill[l] = seen_token_prev

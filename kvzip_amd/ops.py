@@ -60,7 +60,7 @@ def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int,
     if out is None:
         out = torch.empty((1, Hkv, m), dtype=query_states.dtype, device=query_states.device)
     assert out.stride(-1) == 1 and out.shape[-1] == m
-    need = lib.kvz_score_workspace_bytes(Hkv, G, q_len, m)
+    need = lib.kvz_score_workspace_bytes(Hkv, G, q_len, m, sink)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=query_states.device)
     rc = lib.kvz_score_chunk(query_states.data_ptr(), query_states.stride(1), key_states.data_ptr(),

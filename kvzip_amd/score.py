@@ -73,7 +73,7 @@ class KVScore:
         self._ensure_score_capacity(f + m)
         out = self._score_buf[layer_idx][:, :, f:f + m]
         bsz, H, q_len, D = query_states.shape
-        need = ops._lib.load().kvz_score_workspace_bytes(self.n_heads_kv, H // self.n_heads_kv, q_len, m)
+        need = ops._lib.load().kvz_score_workspace_bytes(self.n_heads_kv, H // self.n_heads_kv, q_len, m, self.sink)
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = torch.empty(need, dtype=torch.uint8, device=query_states.device)
         ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,

@@ -39,9 +39,9 @@ def test_host_only_entry_points():
     assert lib.kvz_abi_version() == 1
     assert lib.kvz_select_workspace_bytes() >= (2048 + 32) * 4
     assert lib.kvz_compact_plan_bytes(28, 4, 131104) == 28 * 4 * 129 * 4
-    assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4
+    assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000, 32) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4
     assert lib.kvz_varlen_attn_workspace_bytes(4, 7, 1, 128, 131104) > 0
-    assert lib.kvz_score_workspace_bytes(0, 7, 1, 1) == 0
+    assert lib.kvz_score_workspace_bytes(0, 7, 1, 1, 0) == 0
 
 
 def test_argument_validation_without_gpu():

@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the N>1 path = context sharding + the result-record gather (the only
+exchange the path has).  Compute is GPU-only, so records are synthetic here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kvzip_amd.dist import gather_results, pack_record, shard_contexts, unpack_record
+
+
+def test_shard_contexts_partition():
+    for n, w in ((8, 8), (8, 2), (5, 2), (3, 4), (0, 2)):
+        parts = [shard_contexts(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_record_round_trip():
+    len_k = torch.arange(28 * 4, dtype=torch.int32).view(28, 4) * 1000 + 7
+    rec = pack_record(0.1259765625, 0.2998, len_k)
+    out = unpack_record(rec, 28, 4)
+    assert out["thres"] == 0.1259765625 and out["real_ratio"] == 0.2998
+    assert torch.equal(out["len_k"], len_k) and out["n_kept"] == int(len_k.sum())
+
+
+def _worker(rank, world, port, n_ctx, L, Hkv, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_contexts(n_ctx, rank, world)
+    recs = [pack_record(0.5 + ctx, 0.25 + 0.01 * ctx, torch.full((L, Hkv), 100 * ctx + 3, dtype=torch.int32))
+            for ctx in mine]
+    out = gather_results(recs, n_ctx, L, Hkv)
+    ok = all(o["thres"] == 0.5 + c and abs(o["real_ratio"] - (0.25 + 0.01 * c)) < 1e-12 and
+             int(o["len_k"][0, 0]) == 100 * c + 3 and o["n_kept"] == L * Hkv * (100 * c + 3) for c, o in enumerate(out))
+    q.put((rank, ok, len(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ctx", [2, 5])
+def test_gather_results_world2_gloo(n_ctx):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ctx, 3, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(ok and n == n_ctx for _, ok, n in res)

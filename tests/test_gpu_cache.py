@@ -1,0 +1,191 @@
+"""GPU: the drop-in cache objects (kvzip_amd.EvictCache / RetainCache) replay the reference's EvictCache life
+cycle recorded in tests/golden/g6_cache_*.npz: scoring -> prune -> query prefill (t=7) -> 2 decode steps -> slice.
+Integer / byte results are bit-exact; scores and attention outputs carry their stated tolerance."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import from_bits, load_golden, to_bits, ulp_diff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(L, H, Hkv):
+    return types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+
+
+def _run_scoring(kv, g, L, sink, bf):
+    chunks = [(sink, sink + 50), (sink + 50, sink + 80)]
+    kv.init_score()
+    for ci, (st, en) in enumerate(chunks):
+        kv.start_idx, kv.end_idx = st, en
+        seen = kv._seen_tokens
+        for l in range(L):
+            q = from_bits(g[f"sc/{ci}/{l}/q"], bf).to(DEV)
+            kr = from_bits(g[f"sc/{ci}/{l}/k"], bf).to(DEV)
+            vr = from_bits(g[f"sc/{ci}/{l}/v"], bf).to(DEV)
+            kfull, _ = kv.update(kr, vr, l)
+            assert kfull.shape[2] == seen + kr.shape[2]
+            kv._get_score(q, kfull, l)
+        kv.slice(seen)
+        assert kv._seen_tokens == seen and kv.key_cache[0].shape[2] == seen
+    kv.start_idx, kv.get_score = sink, False
+
+
+@pytest.mark.parametrize("tag", ["f16_pair", "bf16_pair", "f16_uniform"])
+@pytest.mark.parametrize("layout", ["packed", "slack"])
+def test_evict_cache_life_cycle(tag, layout):
+    from kvzip_amd.kvcache import EvictCache
+    g = load_golden(f"g6_cache_{tag}.npz")
+    L, H, Hkv, D, sink, N, bf = g["meta"].tolist()
+    G = H // Hkv
+    dt = torch.bfloat16 if bf else torch.float16
+    level = "pair-uniform" if "uniform" in tag else "pair"
+    kv = EvictCache(_cfg(L, H, Hkv), (sink, sink + N), device=DEV, dtype=dt, layout=layout, slack=16, reserve=8,
+                    verbose=False)
+    assert kv.get_seq_length() == 0
+    for l in range(L):
+        K, V = kv.update(from_bits(g[f"K0/{l}"], bf).to(DEV), from_bits(g[f"V0/{l}"], bf).to(DEV), l)
+        assert np.array_equal(to_bits(K), g[f"K0/{l}"])
+    assert kv.get_seq_length() == sink + N and kv._seen_tokens == sink + N
+    _run_scoring(kv, g, L, sink, bf)
+    # scores: rounding-chain tolerance (see tests/test_gpu_kernels.py::test_score_chunk_golden)
+    for l in range(L):
+        assert kv.score[l].shape == (1, Hkv, N)
+        d = ulp_diff(kv.score[l], from_bits(g[f"score/{l}"], bf))
+        assert (d <= 1).float().mean() >= 0.99 and d.max() <= 8
+    # integer-exact part: selection + compaction from the REFERENCE's scores
+    kv.score = [from_bits(g[f"score/{l}"], bf).to(DEV) for l in range(L)]
+    ratio = float(g["ratio"][0])
+    thres, r_real = kv.prune(ratio, level)
+    assert thres == g["thres"][0] and r_real == g["r_real"][0]
+    assert np.array_equal(kv.valid.cpu().numpy(), g["valid"])
+    assert kv.pruned and kv.info["flatten"]
+    assert kv._mem() == g["mem_gb"][0]
+    for l in range(L):
+        assert np.array_equal(kv.info["len_k"][l].cpu().numpy(), g[f"len_k/{l}"])
+        assert kv.info["max_len_k"][l] == int(g[f"max_len_k/{l}"][0])
+        cu = g[f"cu_len_k/{l}"]
+        seg = kv.info["seg_start"][l].cpu().numpy()
+        for h in range(Hkv):
+            n = int(cu[h + 1] - cu[h])
+            assert np.array_equal(to_bits(kv.key_cache[l][seg[h]:seg[h] + n]), g[f"flatK/{l}"][cu[h]:cu[h + 1]])
+            assert np.array_equal(to_bits(kv.value_cache[l][seg[h]:seg[h] + n]), g[f"flatV/{l}"][cu[h]:cu[h + 1]])
+        if layout == "packed":
+            assert np.array_equal(kv.info["cu_len_k"][l].cpu().numpy(), cu)
+            assert np.array_equal(to_bits(kv.key_cache[l]), g[f"flatK/{l}"])
+    # generation: query prefill of 7 tokens, then two decode steps (reference model/wrapper.py:251-284)
+    seen = kv._seen_tokens
+    for si, t in enumerate((7, 1, 1)):
+        for l in range(L):
+            q = from_bits(g[f"gen/{si}/{l}/q"], bf).to(DEV)
+            kn = from_bits(g[f"gen/{si}/{l}/k"], bf).to(DEV)
+            vn = from_bits(g[f"gen/{si}/{l}/v"], bf).to(DEV)
+            ke, ve = kv.update(kn, vn, l)
+            qe, ke2, ve2, info = kv.prepare(q, ke, ve, l)
+            assert np.array_equal(to_bits(qe), g[f"gen/{si}/{l}/q_out"])
+            assert np.array_equal(info["cu_len_q"].cpu().numpy(), g[f"gen/{si}/{l}/cu_len_q"])
+            assert [info["max_len_q"], info["max_len_k"]] == g[f"gen/{si}/{l}/max_len"].tolist()
+            cu = g[f"gen/{si}/{l}/cu_len_k"]
+            if layout == "packed":
+                assert np.array_equal(info["cu_len_k"].cpu().numpy(), cu)
+                assert np.array_equal(to_bits(ke2.view(-1, D)), g[f"gen/{si}/{l}/k_out"])
+                assert np.array_equal(to_bits(ve2.view(-1, D)), g[f"gen/{si}/{l}/v_out"])
+            else:
+                seg = info["k_start"].cpu().numpy()
+                ln = info["k_len"].cpu().numpy() + info["k_len_offset"]
+                for h in range(Hkv):
+                    assert ln[h] == cu[h + 1] - cu[h]
+                    assert np.array_equal(to_bits(ke2.view(-1, D)[seg[h]:seg[h] + ln[h]]),
+                                          g[f"gen/{si}/{l}/k_out"][cu[h]:cu[h + 1]])
+            att = kv.attend(qe, ke2, ve2, info)
+            want = from_bits(g[f"gen/{si}/{l}/attn"], bf).float()
+            tol = 8e-3 if bf else 1e-3
+            assert (att.cpu().float() - want).abs().max() <= tol
+    assert [kv._seen_tokens, kv.get_seq_length()] == g["seen_after_gen"].tolist()
+    kv.slice(seen)
+    assert kv._seen_tokens == g["seen_after_slice"][0]
+    assert kv.info["offset"] == [0] * L
+    for l in range(L):
+        if layout == "packed":
+            assert np.array_equal(to_bits(kv.key_cache[l]), g[f"sliced/K/{l}"])
+            assert np.array_equal(kv.info["cu_len_k"][l].cpu().numpy(), g[f"sliced/cu_len_k/{l}"])
+
+
+@pytest.mark.parametrize("tag", ["f16_pair", "f16_uniform"])
+def test_retain_cache_equals_evict_cache(tag):
+    """The reference's internal cross-check: RetainCache.prepare == EvictCache compacted path."""
+    from kvzip_amd.kvcache import EvictCache, RetainCache
+    g = load_golden(f"g6_cache_{tag}.npz")
+    L, H, Hkv, D, sink, N, bf = g["meta"].tolist()
+    dt = torch.bfloat16 if bf else torch.float16
+    level = "pair-uniform" if "uniform" in tag else "pair"
+    caches = [EvictCache(_cfg(L, H, Hkv), (sink, sink + N), device=DEV, dtype=dt, layout="packed", verbose=False),
+              RetainCache(_cfg(L, H, Hkv), (sink, sink + N), device=DEV, dtype=dt, verbose=False)]
+    for kv in caches:
+        for l in range(L):
+            kv.update(from_bits(g[f"K0/{l}"], bf).to(DEV), from_bits(g[f"V0/{l}"], bf).to(DEV), l)
+        kv.score = [from_bits(g[f"score/{l}"], bf).to(DEV) for l in range(L)]
+    r0 = caches[0].prune(0.4, level)
+    r1 = caches[1].prune(0.4, level)
+    assert r0 == r1 and torch.equal(caches[0].valid, caches[1].valid)
+    for si, t in enumerate((7, 1)):
+        for l in range(L):
+            q = from_bits(g[f"gen/{si}/{l}/q"], bf).to(DEV)
+            kn = from_bits(g[f"gen/{si}/{l}/k"], bf).to(DEV)
+            vn = from_bits(g[f"gen/{si}/{l}/v"], bf).to(DEV)
+            outs = []
+            for kv in caches:
+                ke, ve = kv.update(kn, vn, l)
+                outs.append(kv.prepare(q, ke, ve, l))
+            (qe, ke, ve, ie), (qr, kr, vr, ir) = outs
+            assert torch.equal(qe, qr) and torch.equal(ke, kr) and torch.equal(ve, vr)
+            assert torch.equal(ie["cu_len_k"], ir["cu_len_k"]) and ie["max_len_k"] == ir["max_len_k"]
+            assert np.array_equal(to_bits(ke.view(-1, D)), g[f"gen/{si}/{l}/k_out"])
+            a0 = caches[0].attend(qe, ke, ve, ie)
+            a1 = caches[1].attend(qr, kr, vr, ir)
+            assert torch.equal(a0, a1)
+
+
+def test_head_level_prune_config5_shape():
+    """--level head path (model/wrapper.py:40-58): scores given as an expanded [L,1,Hkv,N] tensor."""
+    from kvzip_amd.kvcache import EvictCache
+    g = load_golden("g4_head_score.npz")
+    hs = from_bits(g["qwen2.5-14b/head_score"], True)           # [48, 8] bf16
+    L, Hkv = hs.shape
+    N, sink, D = 1000, 4, 64
+    kv = EvictCache(_cfg(L, Hkv * 5, Hkv), (sink, sink + N), device=DEV, dtype=torch.bfloat16, verbose=False)
+    for l in range(L):
+        kv.update(torch.randn(1, Hkv, sink + N, D, dtype=torch.bfloat16, device=DEV),
+                  torch.randn(1, Hkv, sink + N, D, dtype=torch.bfloat16, device=DEV), l)
+    kv.score = hs.to(DEV).unsqueeze(-1).expand(-1, -1, N).unsqueeze(1)  # as load_head_score returns it
+    thres, r_real = kv.prune(0.6, "head")
+    assert thres == 0.53515625
+    kept = g["qwen2.5-14b/kept/1000/0.6"]
+    assert kept.sum() == 229
+    for l in range(L):
+        assert np.array_equal(kv.info["len_k"][l].cpu().numpy(), sink + kept[l].astype(np.int32) * N)
+
+
+def test_slack_growth_and_update_after_many_tokens():
+    from kvzip_amd.kvcache import EvictCache
+    L, H, Hkv, D, sink, N = 1, 4, 2, 64, 2, 64
+    kv = EvictCache(_cfg(L, H, Hkv), (sink, sink + N), device=DEV, dtype=torch.float16, slack=4, verbose=False)
+    K = torch.randn(1, Hkv, sink + N, D, device=DEV).half()
+    kv.update(K, K.clone(), 0)
+    kv.score = [torch.rand(1, Hkv, N, device=DEV).half()]
+    kv.prune(0.5)
+    lens = kv.info["len_k_host"][0]
+    news = []
+    for step in range(9):  # exceeds the slack of 4 -> re-layout
+        kn = torch.randn(1, Hkv, 1, D, device=DEV).half()
+        news.append(kn)
+        ke, ve = kv.update(kn, kn, 0)
+        kv.prepare(torch.randn(1, H, 1, D, device=DEV).half(), ke, ve, 0)
+    seg = kv.info["seg_start"][0].tolist()
+    for h in range(Hkv):
+        tail = kv.key_cache[0][seg[h] + lens[h]: seg[h] + lens[h] + 9]
+        assert torch.equal(tail, torch.cat([n[0, h] for n in news]))

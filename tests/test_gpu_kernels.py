@@ -382,3 +382,35 @@ def test_varlen_attn_compaction_identity():
     full = orc.get_valid(valid[0], 0, klen)[0]
     want = orc.dense_masked_attn(q, k[0], v[0], full, q_len)
     assert (got.float() - want.float()).abs().max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 rounding chain: exhaustive over all 65536 16-bit inputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D", [64, 128])
+def test_round_chain_exhaustive(dtype, D):
+    """half(x / float32(sqrt(D))) for EVERY 16-bit x: the kernels' exact-reciprocal multiply and their IEEE-division
+    fallback both reproduce torch's CPU result (tensor / python float, fp32 opmath) bit for bit."""
+    import ctypes as C
+    from kvzip_amd import _lib
+    lib = _lib.load()
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dtype)
+    want = (x / math.sqrt(D))
+    finite = torch.isfinite(x.float())
+    for force_div in (0, 1):
+        out = torch.empty(65536, dtype=torch.int16, device=DEV)
+        rcp = C.c_float(0)
+        rc = lib.kvz_debug_round_chain(bits.to(DEV).data_ptr(), 65536, D, 0 if dtype == torch.float16 else 1, force_div,
+                                       out.data_ptr(), C.byref(rcp), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out.cpu().view(dtype)
+        # (the fused multiply path returns +0 for x = -0: equal as values, irrelevant for the softmax)
+        same = (got.view(torch.int16) == want.view(torch.int16)) | ~finite | ((got.float() == 0) & (want.float() == 0))
+        bad = torch.nonzero(~same).view(-1)[:8]
+        assert same.all(), (dtype, D, force_div, int((~same).sum()), bad.tolist(), x[bad].tolist(),
+                            got[bad].tolist(), want[bad].tolist())
+        if not force_div:
+            assert rcp.value != 0.0, "no exact reciprocal found: kernels would fall back to the slow division"

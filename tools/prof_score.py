@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Micro-driver for profiling: a few kvz_score_chunk / compaction / decode-attention launches at the bench geometry
+(Qwen2.5-7B, one layer).  Used under rocprofv3 --pmc (counter passes are slow, so this keeps the launch count small)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kvzip_amd import ops  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "score"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = "cuda:0"
+H, Hkv, D, sink, N, m = 28, 4, 128, 32, 131072, 2000
+q_len = m + 26
+klen = sink + N + q_len
+g = torch.Generator(device=dev).manual_seed(0)
+dt = torch.float16
+if what == "score":
+    q = torch.randn(1, H, q_len, D, generator=g, device=dev).to(dt)
+    k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
+    start = sink + 60000
+    for _ in range(2):
+        ops.score_chunk(q, k, sink, start, start + m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ops.score_chunk(q, k, sink, start, start + m)
+    torch.cuda.synchronize()
+    print(f"score_chunk: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
+elif what == "attn":
+    G = H // Hkv
+    lens = torch.tensor([39000, 39500, 38800, 39900], dtype=torch.int32, device=dev)
+    slack = 1024
+    starts = torch.tensor([0, 40024, 40024 * 2, 40024 * 3 + 500], dtype=torch.int32, device=dev)
+    rows = 40024 * 4 + 2000
+    k = torch.randn(rows, D, generator=g, device=dev).to(dt)
+    v = torch.randn(rows, D, generator=g, device=dev).to(dt)
+    q = torch.randn(Hkv, G, D, generator=g, device=dev).to(dt)
+    for _ in range(2):
+        ops.varlen_attn(q, k, v, starts, lens, 1, 39900)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ops.varlen_attn(q, k, v, starts, lens, 1, 39900)
+    torch.cuda.synchronize()
+    print(f"varlen_attn: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
