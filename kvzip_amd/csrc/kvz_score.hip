@@ -40,11 +40,14 @@ template <> struct Mfma32<__bf16> {
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int SC_THREADS = 512;  // 8 waves share one streamed tile; 2 blocks per CU -> 4 waves per SIMD (<= 128 VGPRs)
-constexpr int SC_WAVES = SC_THREADS / 64;
-constexpr int SC_TILE = 128;     // streamed rows per LDS tile
-constexpr int SC_COLS = SC_WAVES * 32;  // stationary columns per block (32 per wave)
-constexpr int SC_KSPLIT_TILES = 8;  // pass A: key tiles per block (load balance under the causal mask)
+constexpr int SC_TILE = 128;     // streamed rows per LDS tile (2 x 32 KiB LDS buffers per block -> 2 blocks per CU)
+// pass A: 4 waves / block, 2 waves per SIMD, up to 256 VGPRs: deep register prefetch of the A fragments
+// pass B: 8 waves / block, 4 waves per SIMD, <= 128 VGPRs
+constexpr int PA_WAVES = 4, PB_WAVES = 8;
+#ifndef KVZ_KSPLIT_TILES
+#define KVZ_KSPLIT_TILES 8
+#endif
+constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;  // pass A: key tiles per block (load balance under the causal mask)
 
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
@@ -59,9 +62,6 @@ struct ScoreArgs {
     int row_splits;      // pass B
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
-#ifdef KVZ_TRACE
-    unsigned long long* trace;  // debug build only: per-block timestamps
-#endif
 };
 
 // reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
@@ -75,6 +75,31 @@ __device__ static inline float round_chain(float acc, float c, float rcp) {
     const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
     const T h2 = (T)d;
     return (float)h2;
+}
+
+// the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
+// arguments read it through the mixed-precision fma: no separate conversion back to fp32)
+template <typename T, bool FAST>
+__device__ static inline T round_chain_h(float acc, float c, float rcp) {
+    const T h1 = (T)acc;
+    const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
+    return (T)d;
+}
+// maximum of 16 values of T as fp32 (fp16: packed v_pk_max_f16 on pairs)
+template <typename T>
+__device__ static inline float max16(const T (&hx)[16]) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        h2v m = {hx[0], hx[1]};
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) m = __builtin_elementwise_max(m, h2v{hx[i], hx[i + 1]});
+        return fmaxf((float)m[0], (float)m[1]);
+    } else {
+        float m = (float)hx[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, (float)hx[i]);
+        return m;
+    }
 }
 
 template <int D> struct ScoreCfg {
@@ -97,16 +122,16 @@ template <int D> struct ScoreCfg {
 // downstream (causal limit in pass A, m = +inf statistics in pass B).
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-template <int D, typename RowPtr>
+template <int D, int NW, typename RowPtr>
 __device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int wave, int lane) {
     typedef ScoreCfg<D> C;
     constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;  // 4 (D = 128) or 8 (D = 64)
     constexpr int INSTR = C::TILE_BYTES / 1024;
-    constexpr int PER_WAVE = INSTR / SC_WAVES;
-    static_assert(PER_WAVE >= 1 && INSTR % SC_WAVES == 0, "tile / wave layout");
+    constexpr int PER_WAVE = INSTR / NW;
+    static_assert(PER_WAVE >= 1 && INSTR % NW == 0, "tile / wave layout");
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-        const int ci = i * SC_WAVES + wave;  // wave-uniform 1-KiB piece of the tile
+        const int ci = i * NW + wave;  // wave-uniform 1-KiB piece of the tile
         const int row = ci * ROWS_PER_INSTR + lane / C::CPR;
         const int p = lane % C::CPR;
         const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
@@ -120,7 +145,9 @@ __device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int
 // is exp2(fma(x, log2e, -ml2)) (one rounding), and the common factor 2^(m*log2e - ml2) that this introduces
 // into l is removed exactly at the end (delta = fma(m, log2e, -ml2)).
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PA_WAVES * 64, 2) void score_rowstat_kernel(ScoreArgs a) {
+    constexpr int NWAVES = PA_WAVES;
+    constexpr int SC_COLS = NWAVES * 32;  // stationary query rows per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES];
@@ -132,9 +159,6 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-#ifdef KVZ_TRACE
-    unsigned long long tr0 = wall_clock64(), tr1 = 0, tr2 = 0;
-#endif
 
     // stationary operand: 32 query rows per wave, one per lane (B operand: col = row index)
     const int r = blockIdx.x * SC_COLS + wave * 32 + l31;
@@ -162,7 +186,10 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs 
         kend = min(KT, a.sink + a.m + qmax + 1);
     }
     const int ntiles = (kend + SC_TILE - 1) / SC_TILE;
-    const int t_lo = blockIdx.z * SC_KSPLIT_TILES;
+    // dispatch order follows blockIdx.z: run the LAST key slices (masked, diagonal tiles) first so that the tail of
+    // the launch consists of the cheapest blocks
+    const int zslice = (int)gridDim.z - 1 - (int)blockIdx.z;
+    const int t_lo = zslice * SC_KSPLIT_TILES;
     const int t_hi = min(ntiles, t_lo + SC_KSPLIT_TILES);
 
     const char* kh = reinterpret_cast<const char*>(a.k) + (int64_t)h * a.k_head_stride * 2;
@@ -178,28 +205,37 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs 
     const int diag0 = a.sink + a.m;  // first key that can be masked for some row
 
     // one 128-key tile = 4 blocks of 32 keys; MASK = tile straddles / lies beyond the causal diagonal
+    // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use, so
+    // that the matrix chain never waits for LDS latency (sched_barrier pins the order: the compiler would otherwise
+    // sink every ds_read next to its MFMA and serialise read latency + MFMA eight times per block)
+    auto load_frags = [&](u32x4 (&fr)[C::KK], const char* buf, int kb) {
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk)
+            fr[kk] = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
+    };
     auto tile_body = [&](const char* buf, int t, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        u32x4 fr[C::KK];
+        load_frags(fr, buf, 0);
 #pragma unroll
         for (int kb = 0; kb < SC_TILE / 32; ++kb) {
             f16v acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
-                acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, raw), bq[kk], acc);
-            }
-            float x[16];
-            float tmax = -INFINITY;
+            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kk]), bq[kk], acc);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            T x[16];
             const int rel = limit - (t * SC_TILE + kb * 32 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float v = round_chain<T, FAST>(acc[i], a.c, a.rcp);
-                if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : -INFINITY;
+                T v = round_chain_h<T, FAST>(acc[i], a.c, a.rcp);
+                if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : (T)(-INFINITY);
                 x[i] = v;
-                tmax = fmaxf(tmax, v);
             }
+            const float tmax = max16<T>(x);
             if (tmax > m_run) {  // new running maximum: rescale the partial sum
                 const float ml2_new = tmax * L2E;
                 l_run *= __builtin_amdgcn_exp2f(ml2_run - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
@@ -209,41 +245,25 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs 
             float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
-                ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], L2E, -ml2_run));
-                ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[i + 1], L2E, -ml2_run));
+                ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i], L2E, -ml2_run));
+                ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i + 1], L2E, -ml2_run));
             }
             l_run += ps0 + ps1;  // (all-masked so far: x = -inf -> exp2(-inf) = 0)
         }
     };
 
     if (t_lo < t_hi) {
-        stage_tile<D>(lds, t_lo * SC_TILE, keyptr, wave, lane);
+        stage_tile<D, NWAVES>(lds, t_lo * SC_TILE, keyptr, wave, lane);
         __syncthreads();
-#ifdef KVZ_TRACE
-        tr1 = wall_clock64();
-#endif
         for (int t = t_lo; t < t_hi; ++t) {
             const int cur = (t - t_lo) & 1;
             const char* buf = lds + cur * C::TILE_BYTES;
-            if (t + 1 < t_hi) stage_tile<D>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, keyptr, wave, lane);
+            if (t + 1 < t_hi) stage_tile<D, NWAVES>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, keyptr, wave, lane);
             if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(buf, t, std::true_type{});   // also covers kv >= KT
             else tile_body(buf, t, std::false_type{});
             __syncthreads();  // next tile landed (vmcnt drained) and everybody is done reading this one
         }
     }
-#ifdef KVZ_TRACE
-    tr2 = wall_clock64();
-    if (threadIdx.x == 0 && a.trace) {
-        const int64_t b = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.trace[b * 6 + 0] = tr0; a.trace[b * 6 + 1] = tr1; a.trace[b * 6 + 2] = tr2;
-        a.trace[b * 6 + 3] = wall_clock64(); a.trace[b * 6 + 4] = ((unsigned long long)xcc << 32) | hwid;
-        a.trace[b * 6 + 5] = (unsigned long long)(t_hi > t_lo ? t_hi - t_lo : 0);
-    }
-#endif
     // merge the two half-waves (they saw disjoint keys of the same query row)
     const float m_o = __shfl_xor(m_run, 32, 64);
     const float ml2_o = __shfl_xor(ml2_run, 32, 64);
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_rowstat_kernel(ScoreArgs 
     const float ML2 = (m_run >= m_o) ? ml2_run : ml2_o;
     const float Lp = l_run * __builtin_amdgcn_exp2f(ml2_run - ML2) + l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
     // partial statistics of this key slice (empty slice: m = -inf, l' = 0)
-    if (half == 0 && rvalid) a.stats[((int64_t)blockIdx.z * gridDim.y + h) * R + r] = make_float2(M, Lp);
+    if (half == 0 && rvalid) a.stats[((int64_t)zslice * gridDim.y + h) * R + r] = make_float2(M, Lp);
 }
 
 // merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
@@ -275,7 +295,9 @@ __global__ void score_merge_stats_kernel(float2* __restrict__ stats, int key_spl
 
 // ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(SC_THREADS, 4) void score_colmax_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArgs a) {
+    constexpr int NWAVES = PB_WAVES;
+    constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_colmax_kernel(ScoreArgs a
 
     float best = -INFINITY;
     if (t_begin < t_end) {
-        stage_tile<D>(lds, t_begin * SC_TILE, rowptr, wave, lane);
+        stage_tile<D, NWAVES>(lds, t_begin * SC_TILE, rowptr, wave, lane);
         float2 sst = load_stat(t_begin);
         if (threadIdx.x < SC_TILE) lstat[threadIdx.x] = sst;
         __syncthreads();
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_colmax_kernel(ScoreArgs a
             const char* buf = lds + cur * C::TILE_BYTES;
             const float2* ls = lstat + cur * SC_TILE;
             if (t + 1 < t_end) {
-                stage_tile<D>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, rowptr, wave, lane);
+                stage_tile<D, NWAVES>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, rowptr, wave, lane);
                 sst = load_stat(t + 1);
             }
 #pragma unroll 1
@@ -349,8 +371,8 @@ __global__ __launch_bounds__(SC_THREADS, 4) void score_colmax_kernel(ScoreArgs a
                 for (int i = 0; i < 16; i += 2) {
                     const int rr = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
                     const float2 s0 = ls[rr], s1 = ls[rr + 1];
-                    b0 = fmaxf(b0, (round_chain<T, FAST>(acc[i], a.c, a.rcp) - s0.x) - s0.y);
-                    b1 = fmaxf(b1, (round_chain<T, FAST>(acc[i + 1], a.c, a.rcp) - s1.x) - s1.y);
+                    b0 = fmaxf(b0, ((float)round_chain_h<T, FAST>(acc[i], a.c, a.rcp) - s0.x) - s0.y);
+                    b1 = fmaxf(b1, ((float)round_chain_h<T, FAST>(acc[i + 1], a.c, a.rcp) - s1.x) - s1.y);
                 }
                 best = fmaxf(best, fmaxf(b0, b1));
             }
@@ -382,9 +404,9 @@ static inline int score_key_splits(int sink, int m, int q_len) {
 }
 // number of row slices of pass B: enough blocks to fill 256 CUs about twice, no empty slice
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
-    const int ctiles = (m + SC_COLS - 1) / SC_COLS;
+    const int ctiles = (m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
-    int splits = (768 + ctiles * Hkv - 1) / (ctiles * Hkv);
+    int splits = 512 / (ctiles * Hkv);  // 256 CUs x 2 resident blocks: exactly one round when the shape allows
     if (splits > rtiles) splits = rtiles;
     if (splits < 1) splits = 1;
     const int per = (rtiles + splits - 1) / splits;
@@ -473,8 +495,8 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     const int R = a.G * a.q_len;
     {
         ProfScope ps("score_rowstat", stream);
-        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3((R + SC_COLS - 1) / SC_COLS, Hkv, a.key_splits),
-                           dim3(SC_THREADS), 0, stream, a);
+        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3((R + PA_WAVES * 32 - 1) / (PA_WAVES * 32), Hkv, a.key_splits),
+                           dim3(PA_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_rowstat_kernel");
     {
@@ -483,11 +505,11 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
                            a.key_splits, rows_total);
     }
     KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
-    const int ctiles = (a.m + SC_COLS - 1) / SC_COLS;
+    const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     {
         ProfScope ps("score_colmax", stream);
-        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles, a.row_splits, Hkv), dim3(SC_THREADS), 0, stream, a);
+        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles, a.row_splits, Hkv), dim3(PB_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
@@ -504,10 +526,6 @@ static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream) {
 
 using namespace kvz;
 
-#ifdef KVZ_TRACE
-static unsigned long long* g_trace = nullptr;
-extern "C" void kvz_debug_set_trace(void* p) { g_trace = (unsigned long long*)p; }
-#endif
 
 static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
     return align256((size_t)score_key_splits(sink, m, q_len) * Hkv * G * q_len * sizeof(float2));
@@ -542,9 +560,6 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     a.key_splits = score_key_splits(sink, m, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
-#ifdef KVZ_TRACE
-    a.trace = g_trace;
-#endif
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
     a.rcp = find_exact_reciprocal(a.c, dtype);
     if (dtype == KVZ_F16) {
