@@ -212,82 +212,83 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     }
 }
 
-// merge the per-split partials.  grid = (Hkv, row tiles, D/32); block = 8 split-slices x 32 columns.
-// Every load in the main loop is independent (split-parallel), so the kernel is throughput- not latency-bound.
-constexpr int CB_SLICES = 8;
+// merge the per-split partials.  grid = (Hkv, row tiles, 16 query rows); block = 1024 threads = (1024/D) split
+// slices x D columns.  Every load of the main loop is independent (split-parallel): throughput-, not latency-bound.
+constexpr int CB_THREADS = 1024;
 template <typename T, int D>
-__global__ __launch_bounds__(AT_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
+__global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
                                                                         const float* __restrict__ part_ml,
                                                                         const int32_t* __restrict__ k_len,
                                                                         int k_len_offset, int G,
                                                                         int q_len, int chunk, int n_splits,
                                                                         int n_rtiles, T* __restrict__ out) {
-    const int h = blockIdx.x, rt = blockIdx.y, dblk = blockIdx.z;
+    constexpr int SLICES = CB_THREADS / D;
+    const int h = blockIdx.x, rt = blockIdx.y, qq = blockIdx.z;
     const int R = q_len * G;
+    if (rt * AT_RT + qq >= R) return;
     const int len = k_len[h] + k_len_offset;
     const int nsp = (len + chunk - 1) / chunk;
-    const int rows = min(AT_RT, R - rt * AT_RT);
-    const int64_t base = ((int64_t)h * n_rtiles + rt) * n_splits * AT_RT;
+    const int64_t base = (((int64_t)h * n_rtiles + rt) * n_splits) * AT_RT + qq;  // + s * AT_RT
     const int tid = threadIdx.x;
-    const int dl = tid & 31, slice = tid >> 5;
+    const int d = tid % D, slice = tid / D;
 
-    __shared__ float s_max[AT_RT][AT_RT + 1];
-    __shared__ float s_M[AT_RT];
-    __shared__ float s_acc[CB_SLICES][AT_RT][33];
-    __shared__ float s_l[CB_SLICES][AT_RT];
+    __shared__ float s_red[CB_THREADS / WAVE];
+    __shared__ float s_acc[SLICES][D];
+    __shared__ float s_M, s_L;
 
-    // global maximum per query row
-    {
-        const int qq = tid & 15, grp = tid >> 4;  // 16 groups stride over the splits
-        float mx = -INFINITY;
-        for (int s = grp; s < nsp; s += 16) mx = fmaxf(mx, part_ml[(base + (int64_t)s * AT_RT + qq) * 2]);
-        s_max[grp][qq] = mx;
+    // global maximum of the row over all splits
+    float mx = -INFINITY;
+    for (int s = tid; s < nsp; s += CB_THREADS) mx = fmaxf(mx, part_ml[(base + (int64_t)s * AT_RT) * 2]);
+    mx = wave_reduce_max(mx);
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < CB_THREADS / WAVE; ++w) m2 = fmaxf(m2, s_red[w]);
+        s_M = m2;
     }
     __syncthreads();
-    if (tid < AT_RT) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) mx = fmaxf(mx, s_max[g2][tid]);
-        s_M[tid] = mx;
+    const float M = s_M;
+    // denominator
+    float lp = 0.f;
+    for (int s = tid; s < nsp; s += CB_THREADS) {
+        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (base + (int64_t)s * AT_RT) * 2);
+        lp += (ml.x == -INFINITY) ? 0.f : exp2f(ml.x - M) * ml.y;
     }
-    __syncthreads();
-
-    float acc[AT_RT];
-    float lacc[AT_RT];
 #pragma unroll
-    for (int qq = 0; qq < AT_RT; ++qq) { acc[qq] = 0.f; lacc[qq] = 0.f; }
-    const int d = dblk * 32 + dl;
-    for (int s = slice; s < nsp; s += CB_SLICES) {
+    for (int o = 32; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = lp;
+    __syncthreads();
+    if (tid == 0) {
+        float l2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < CB_THREADS / WAVE; ++w) l2 += s_red[w];
+        s_L = l2;
+    }
+    // numerator: this thread's column over its slice of the splits
+    float acc = 0.f;
+    for (int s = slice; s < nsp; s += SLICES) {
         const int64_t pi = base + (int64_t)s * AT_RT;
-#pragma unroll
-        for (int qq = 0; qq < AT_RT; ++qq) {
-            if (qq < rows) {
-                const float2 ml = *reinterpret_cast<const float2*>(part_ml + (pi + qq) * 2);
-                const float wgt = (ml.x == -INFINITY) ? 0.f : exp2f(ml.x - s_M[qq]);
-                acc[qq] += wgt * part_o[(pi + qq) * D + d];
-                lacc[qq] += wgt * ml.y;
-            }
-        }
+        const float ms = part_ml[pi * 2];
+        const float wgt = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
+        acc += wgt * part_o[pi * D + d];
     }
-#pragma unroll
-    for (int qq = 0; qq < AT_RT; ++qq) {
-        s_acc[slice][qq][dl] = acc[qq];
-        if (dl == 0) s_l[slice][qq] = lacc[qq];
-    }
+    s_acc[slice][d] = acc;
     __syncthreads();
-    for (int e = tid; e < rows * 32; e += AT_THREADS) {
-        const int qq = e >> 5, dd = e & 31;
-        float a = 0.f, l = 0.f;
+    if (tid < D) {
+        float a = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < CB_SLICES; ++sl) { a += s_acc[sl][qq][dd]; l += s_l[sl][qq]; }
-        const float r = (l > 0.f) ? a / l : 0.f;
-        out[((int64_t)h * R + rt * AT_RT + qq) * D + dblk * 32 + dd] = (T)r;
+        for (int sl = 0; sl < SLICES; ++sl) a += s_acc[sl][tid];
+        const float l = s_L;
+        out[((int64_t)h * R + rt * AT_RT + qq) * D + tid] = (T)((l > 0.f) ? a / l : 0.f);
     }
 }
 
 static inline int attn_chunk(int Hkv, int max_len_k) {
-    // aim for ~768 (head, chunk) work items (3 blocks per CU); chunk is a multiple of one block-iteration (128 keys)
-    int64_t c = ((int64_t)Hkv * max_len_k + 767) / 768;
+    // aim for ~512 (head, chunk) work items (2 blocks per CU); chunk is a multiple of one block-iteration (128 keys)
+    int64_t c = ((int64_t)Hkv * max_len_k + 511) / 512;
     c = (c + 127) / 128 * 128;
     if (c < 128) c = 128;
     return (int)c;
@@ -307,7 +308,7 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
                        reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
                        k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
     KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
-    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles, D / 32), dim3(AT_THREADS), 0, stream, part_o,
+    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles, AT_RT), dim3(CB_THREADS), 0, stream, part_o,
                        part_ml, k_len, k_len_offset, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
     KVZ_CHECK_LAUNCH("varlen_attn_combine_kernel");
     return KVZ_OK;
