@@ -168,9 +168,11 @@ int kvz_update_flatten_view(const void* cache, const void* state,
  *   cache[seg_start[h] + base_len[h] + len_offset + i, :] = state[h, i, :]    i in [0,t)
  * base_len is the device-resident len_k of the pruned cache; len_offset is the reference's host-side
  * info["offset"][layer] (attention/kvcache.py:58), so no device-side bookkeeping is needed per token.
- * state rows contiguous, head stride state_head_stride elements. Both K and V in one launch. */
+ * k_state / v_state are [Hkv, t, D] views with arbitrary head and row strides (elements; D contiguous), so K after
+ * RoPE and V straight out of the projection can be appended without a copy.  Both K and V in one launch. */
 int kvz_append_inplace(void* k_cache, void* v_cache,
-                       const void* k_state, const void* v_state, int64_t state_head_stride,
+                       const void* k_state, const void* v_state,
+                       int64_t k_head_stride, int64_t k_row_stride, int64_t v_head_stride, int64_t v_row_stride,
                        const int32_t* seg_start, const int32_t* base_len, int len_offset,
                        int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream);
 

@@ -35,7 +35,7 @@ SIGNATURES = {
     "kvz_compact_layer": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_compact_layers": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
 }

@@ -1,0 +1,80 @@
+"""Attention forward with the three cache hooks — counterpart of the reference's ``llama_qwen_attn_forward``
+(reference attention/attn.py:19-96) written against transformers 5.x (``past_key_values`` keyword, attention
+interface registry).  Hooks on the cache object, in this order (attention/attn.py:44-73):
+
+    update()      append the new K,V                                   (always)
+    _get_score()  KV importance of the current scoring chunk           (if cache.get_score)
+    prepare()+attend()  variable-length attention over the pruned KV   (if cache.pruned)
+
+The dense (pre-prune) attention is NOT on the eviction hot path; the reference delegates it to flash-attn's dense
+kernel (attention/attn.py:75-89).  Here it goes through torch SDPA, registered as the attention implementation
+``"kvzip_hip"`` so that transformers skips its own mask construction (bottom-right aligned causal mask built here).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def dense_causal_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                           scaling: Optional[float] = None, **kwargs):
+    """[b, H, q, D] x [b, Hkv, k, D] -> ([b, q, H, D], None); causal mask aligned to the bottom-right corner
+    (query i sees keys j <= i + k - q), like flash-attn's dense kernel used by the reference."""
+    q_len, k_len = query.shape[-2], key.shape[-2]
+    G = query.shape[1] // key.shape[1]
+    mask, causal = None, False
+    if q_len == k_len:
+        causal = q_len > 1
+    elif q_len > 1:
+        i = torch.arange(q_len, device=query.device).view(q_len, 1)
+        j = torch.arange(k_len, device=query.device).view(1, k_len)
+        mask = j <= i + (k_len - q_len)
+    out = F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scaling,
+                                         enable_gqa=G > 1)
+    return out.transpose(1, 2), None
+
+
+def register_attention_interface():
+    from transformers import AttentionInterface
+    AttentionInterface.register("kvzip_hip", dense_causal_attention)
+
+
+def llama_qwen_attn_forward(self, hidden_states: torch.Tensor,
+                            position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                            attention_mask: Optional[torch.Tensor] = None, past_key_values=None, **kwargs):
+    """Replacement for ``LlamaAttention / Qwen2Attention / Qwen3Attention.forward`` (transformers 5.x signature)."""
+    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb
+
+    bsz, q_len = hidden_states.shape[:2]
+    hidden_shape = (bsz, q_len, -1, self.head_dim)
+    if hasattr(self, "q_norm"):  # Qwen3 (reference attention/attn.py:33-35)
+        query_states = self.q_norm(self.q_proj(hidden_states).view(hidden_shape)).transpose(1, 2)
+        key_states = self.k_norm(self.k_proj(hidden_states).view(hidden_shape)).transpose(1, 2)
+    else:
+        query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+
+    cos, sin = position_embeddings
+    query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+
+    kv = past_key_values
+    if kv is not None:
+        key_states, value_states = kv.update(key_states, value_states, self.layer_idx)
+
+    if getattr(kv, "get_score", None):  # calculate KV importance (attention/attn.py:53-54)
+        kv._get_score(query_states.contiguous(), key_states, self.layer_idx)
+
+    if getattr(kv, "pruned", None):     # attention with the pruned cache (attention/attn.py:56-73)
+        q, k, v, info = kv.prepare(query_states.contiguous(), key_states, value_states, self.layer_idx)
+        attn = kv.attend(q, k, v, info, causal=True, softmax_scale=self.scaling)      # [Hkv*q_len, G, D]
+        n_kv = self.config.num_key_value_heads
+        attn_output = attn.view(bsz, n_kv, q_len, -1, self.head_dim).transpose(1, 2)  # [b, q, Hkv, G, D]
+    else:
+        attn_output, _ = dense_causal_attention(self, query_states, key_states, value_states, None,
+                                                scaling=self.scaling)
+
+    attn_output = attn_output.reshape(bsz, q_len, -1).contiguous()
+    return self.o_proj(attn_output), None

@@ -210,23 +210,28 @@ __global__ __launch_bounds__(256) void update_flatten_view_kernel(const char* __
 }
 
 // ---- O(t) in-place append into per-head slack -----------------------------------------------------
+// state rows may be strided (e.g. V straight out of the projection: [b, t, Hkv, D] viewed as [b, Hkv, t, D])
 __global__ __launch_bounds__(256) void append_inplace_kernel(char* __restrict__ kc, char* __restrict__ vc,
                                                             const char* __restrict__ ks, const char* __restrict__ vs,
-                                                            int64_t state_head_stride_bytes,
+                                                            int64_t k_head_stride_bytes, int64_t k_row_stride_bytes,
+                                                            int64_t v_head_stride_bytes, int64_t v_row_stride_bytes,
                                                             const int32_t* __restrict__ seg_start,
                                                             const int32_t* __restrict__ base_len, int len_offset,
                                                             int t, int row_bytes) {
     const int h = blockIdx.y;
     const int64_t dst_row0 = (int64_t)seg_start[h] + base_len[h] + len_offset;
-    const int64_t chunks = (int64_t)t * row_bytes / 16;
-    const u32x4* k_src = reinterpret_cast<const u32x4*>(ks + (int64_t)h * state_head_stride_bytes);
-    const u32x4* v_src = reinterpret_cast<const u32x4*>(vs + (int64_t)h * state_head_stride_bytes);
-    u32x4* k_dst = reinterpret_cast<u32x4*>(kc + dst_row0 * row_bytes);
-    u32x4* v_dst = reinterpret_cast<u32x4*>(vc + dst_row0 * row_bytes);
+    const int cpr = row_bytes / 16;
+    const int64_t chunks = (int64_t)t * cpr;
+    const char* k_src = ks + (int64_t)h * k_head_stride_bytes;
+    const char* v_src = vs + (int64_t)h * v_head_stride_bytes;
+    char* k_dst = kc + dst_row0 * row_bytes;
+    char* v_dst = vc + dst_row0 * row_bytes;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += stride) {
-        k_dst[i] = k_src[i];
-        v_dst[i] = v_src[i];
+        const int64_t row = i / cpr;
+        const int c = (int)(i % cpr) * 16;
+        *reinterpret_cast<u32x4*>(k_dst + row * row_bytes + c) = *reinterpret_cast<const u32x4*>(k_src + row * k_row_stride_bytes + c);
+        *reinterpret_cast<u32x4*>(v_dst + row * row_bytes + c) = *reinterpret_cast<const u32x4*>(v_src + row * v_row_stride_bytes + c);
     }
 }
 
@@ -340,7 +345,8 @@ extern "C" int kvz_update_flatten_view(const void* cache, const void* state, con
 }
 
 extern "C" int kvz_append_inplace(void* k_cache, void* v_cache, const void* k_state, const void* v_state,
-                                  int64_t state_head_stride, const int32_t* seg_start, const int32_t* base_len,
+                                  int64_t k_head_stride, int64_t k_row_stride, int64_t v_head_stride,
+                                  int64_t v_row_stride, const int32_t* seg_start, const int32_t* base_len,
                                   int len_offset, int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream_) {
     KVZ_REQUIRE(k_cache && v_cache && k_state && v_state && seg_start && base_len, KVZ_EINVAL,
                 "kvz_append_inplace: null pointer");
@@ -349,14 +355,17 @@ extern "C" int kvz_append_inplace(void* k_cache, void* v_cache, const void* k_st
     KVZ_REQUIRE(rb > 0 && rb % 16 == 0, KVZ_EUNSUPPORTED, "kvz_append_inplace: row bytes %d not a multiple of 16", rb);
     KVZ_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(k_state) && aligned16(v_state), KVZ_EINVAL,
                 "kvz_append_inplace: pointers must be 16-byte aligned");
-    KVZ_REQUIRE((state_head_stride * elem_bytes) % 16 == 0, KVZ_EINVAL, "kvz_append_inplace: state head stride unaligned");
+    KVZ_REQUIRE((k_head_stride * elem_bytes) % 16 == 0 && (k_row_stride * elem_bytes) % 16 == 0 &&
+                    (v_head_stride * elem_bytes) % 16 == 0 && (v_row_stride * elem_bytes) % 16 == 0,
+                KVZ_EINVAL, "kvz_append_inplace: state strides must be multiples of 16 bytes");
     int64_t chunks = (int64_t)t * rb / 16;
     int bx = (int)((chunks + 255) / 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(append_inplace_kernel, dim3(bx, Hkv), dim3(256), 0, (hipStream_t)stream_,
                        reinterpret_cast<char*>(k_cache), reinterpret_cast<char*>(v_cache),
                        reinterpret_cast<const char*>(k_state), reinterpret_cast<const char*>(v_state),
-                       state_head_stride * elem_bytes, seg_start, base_len, len_offset, t, rb);
+                       k_head_stride * elem_bytes, k_row_stride * elem_bytes, v_head_stride * elem_bytes,
+                       v_row_stride * elem_bytes, seg_start, base_len, len_offset, t, rb);
     KVZ_CHECK_LAUNCH("append_inplace_kernel");
     return KVZ_OK;
 }

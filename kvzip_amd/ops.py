@@ -230,9 +230,10 @@ def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.
     """O(t) append of ``k_state/v_state [1, Hkv, t, D]`` after each head's current rows (slack layout)."""
     lib = _lib.load()
     _, Hkv, t, D = k_state.shape
-    assert k_state.stride(-1) == 1 and k_state.stride(-2) == D and v_state.stride() == k_state.stride()
+    assert k_state.stride(-1) == 1 and v_state.stride(-1) == 1 and v_state.shape == k_state.shape
     rc = lib.kvz_append_inplace(k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(), v_state.data_ptr(),
-                                k_state.stride(1), seg_start.data_ptr(), base_len.data_ptr(), int(len_offset), Hkv, t, D,
+                                k_state.stride(1), k_state.stride(2), v_state.stride(1), v_state.stride(2),
+                                seg_start.data_ptr(), base_len.data_ptr(), int(len_offset), Hkv, t, D,
                                 k_cache.element_size(), _stream(k_cache))
     check(rc, "kvz_append_inplace")
 
