@@ -95,25 +95,34 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
 
     const float sl2 = scale * 1.44269504088896340736f;  // work in the exp2 domain
 
-    for (int t0 = c0 + wave * AT_KT; t0 < c1; t0 += AT_WAVES * AT_KT) {
-        // ---- issue all HBM loads of this tile: K (MFMA A operands) and V (to be staged) ----------
-        u32x4 kraw[2][C::KK];
+    // HBM loads of one 32-key tile: K rows (MFMA A operands, 16 B per lane) and V rows (to be staged through LDS)
+    auto load_tile = [&](u32x4 (&kr)[2][C::KK], u32x4 (&vr)[C::VLOADS], int t0) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             int key = t0 + sub * 16 + l15;
             key = key < len ? key : len - 1;  // clamp (masked below)
             const char* kp = kbase + (int64_t)key * C::ROW_BYTES + quad * 16;
 #pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) kraw[sub][kk] = *reinterpret_cast<const u32x4*>(kp + kk * 64);
+            for (int kk = 0; kk < C::KK; ++kk) kr[sub][kk] = *reinterpret_cast<const u32x4*>(kp + kk * 64);
         }
-        u32x4 vraw[C::VLOADS];
 #pragma unroll
         for (int it = 0; it < C::VLOADS; ++it) {
             const int c = it * WAVE + lane;
             int key = t0 + c / C::CPR;
             key = key < len ? key : len - 1;
-            vraw[it] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * C::ROW_BYTES + (c % C::CPR) * 16);
+            vr[it] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * C::ROW_BYTES + (c % C::CPR) * 16);
         }
+    };
+    // register double buffering: the next tile's 16 KiB are in flight while the current tile is computed
+    u32x4 kraw[2][C::KK], vraw[C::VLOADS], knext[2][C::KK], vnext[C::VLOADS];
+    {
+        const int tfirst = c0 + wave * AT_KT;
+        if (tfirst < c1) load_tile(kraw, vraw, tfirst);
+    }
+#pragma unroll 1
+    for (int t0 = c0 + wave * AT_KT; t0 < c1; t0 += AT_WAVES * AT_KT) {
+        const int tn = t0 + AT_WAVES * AT_KT;
+        if (tn < c1) load_tile(knext, vnext, tn);
         // ---- S^T = K.Q^T : rows = keys (quad*4+reg within each 16-key sub tile), col = query row ----
         f4 s[2];
 #pragma unroll
@@ -171,6 +180,14 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
                 (__attribute__((address_space(3))) s4*)(trp + 16 * C::VSTRIDE + db * 32));
             s8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             o[db] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, both), pb, o[db]);
+        }
+        if (tn < c1) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int kk = 0; kk < C::KK; ++kk) kraw[sub][kk] = knext[sub][kk];
+#pragma unroll
+            for (int it = 0; it < C::VLOADS; ++it) vraw[it] = vnext[it];
         }
     }
 

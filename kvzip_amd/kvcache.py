@@ -83,11 +83,28 @@ class _CacheBase(KVScore):
                 new = torch.empty((1, old.shape[1], new_cap, old.shape[3]), dtype=old.dtype, device=old.device)
                 new[:, :, :f].copy_(old[:, :, :f])
                 store[layer_idx] = new
-        self._store_k[layer_idx][:, :, f:f + t].copy_(key_states)
-        self._store_v[layer_idx][:, :, f:f + t].copy_(value_states)
+        cap = self._store_k[layer_idx].shape[2]
+        if key_states.is_cuda and key_states.stride(-1) == 1 and value_states.stride(-1) == 1:
+            # one launch for K and V (strided sources accepted): rows f .. f+t of every head segment h*cap
+            seg, zero = self._dense_meta(cap, key_states.device)
+            D = key_states.shape[-1]
+            ops.append_inplace(self._store_k[layer_idx].view(-1, D), self._store_v[layer_idx].view(-1, D), key_states,
+                               value_states, seg, zero, f)
+        else:
+            self._store_k[layer_idx][:, :, f:f + t].copy_(key_states)
+            self._store_v[layer_idx][:, :, f:f + t].copy_(value_states)
         self._fill[layer_idx] = f + t
         self.key_cache[layer_idx] = self._store_k[layer_idx][:, :, :f + t]
         self.value_cache[layer_idx] = self._store_v[layer_idx][:, :, :f + t]
+
+    def _dense_meta(self, cap: int, device):
+        """(segment starts h*cap, zeros) int32 [Hkv] for the dense append launch, cached per capacity."""
+        m = getattr(self, "_dense_meta_cache", None)
+        if m is None or m[0] != cap:
+            seg = torch.arange(self.n_heads_kv, dtype=torch.int32, device=device) * cap
+            m = (cap, seg, torch.zeros(self.n_heads_kv, dtype=torch.int32, device=device))
+            self._dense_meta_cache = m
+        return m[1], m[2]
 
     def adopt_dense(self, store_k: List[torch.Tensor], store_v: List[torch.Tensor], filled: int):
         """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
