@@ -248,6 +248,14 @@ def main():
     decode_bytes = 2.0 * (kept_rows + Hkv * L) * row_bytes                                    # every kept K and V row once per token
     attn_gbs = decode_bytes / L / (attn_ms / attn_n / 1e3) / 1e9 if attn_n else None
 
+    # HBM traffic of the bandwidth-bound kernels, measured offline with PMC counters (separate rocprofv3 --pmc passes,
+    # see profiles/r1_pmc_traffic.json); only attached when the bench runs the geometry it was measured on
+    pmc = {}
+    try:
+        if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+    except (OSError, ValueError):
+        pmc = {}
     out = {
         "metric": "kv_tokens_scored_and_pruned_per_s", "value": world * N * args.steps / elapsed, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -275,10 +283,13 @@ def main():
             "select": {"bound": "hbm", "achieved": s_gbs, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS, "avg_ms": s_ms,
                        "launches": s_n},
             "compact_gather": {"bound": "hbm", "achieved": c_gbs, "unit": "GB/s", "frac": c_gbs / HBM_PEAK_GBS,
-                               "avg_ms": c_ms, "launches": c_n},
+                               "avg_ms": c_ms, "launches": c_n, "algorithmic_bytes": compact_bytes,
+                               "traffic": pmc.get("compact_gather", {}).get("traffic_bytes")},
             "decode_varlen_attn": {"bound": "hbm", "achieved": attn_gbs, "unit": "GB/s",
                                    "frac": (attn_gbs / HBM_PEAK_GBS) if attn_gbs else None,
-                                   "avg_ms": (attn_ms / attn_n) if attn_n else None, "launches": attn_n},
+                                   "avg_ms": (attn_ms / attn_n) if attn_n else None, "launches": attn_n,
+                                   "algorithmic_bytes": decode_bytes / L,
+                                   "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes")},
         },
         "decode": {"tokens_per_s": T / t_dec, "ms_per_token": t_dec / T * 1e3, "tokens": T,
                    "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded"},

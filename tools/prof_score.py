@@ -48,3 +48,21 @@ elif what == "attn":
         ops.varlen_attn(q, k, v, starts, lens, 1, 39900)
     torch.cuda.synchronize()
     print(f"varlen_attn: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
+elif what == "compact":
+    L = 28
+    store_k = [torch.randn(1, Hkv, sink + N, D, generator=g, device=dev).to(dt) for _ in range(L)]
+    store_v = [torch.randn(1, Hkv, sink + N, D, generator=g, device=dev).to(dt) for _ in range(L)]
+    valid = torch.rand(L, 1, Hkv, N, generator=g, device=dev) < 0.3
+    for _ in range(iters):
+        plan = ops.compact_plan(valid, sink, sink + N, slack=1024)
+        totals = (plan.len_k.cpu().sum(-1) + 1024 * Hkv).tolist()
+        ko, vo = ops.compact_layers(store_k, store_v, plan, totals)
+    torch.cuda.synchronize()
+    kept = int(plan.len_k.sum())
+    print(f"compact: kept rows {kept}, algorithmic bytes {2 * 2 * kept * D * 2 + L * Hkv * N}")
+elif what == "select":
+    score = (torch.rand(28, 1, Hkv, N, generator=g, device=dev) ** 8).to(dt)
+    for _ in range(iters):
+        ops.select_threshold(score, 0.3, row_len=N)
+    torch.cuda.synchronize()
+    print("select: algorithmic bytes", 5 * score.numel())
