@@ -6,7 +6,8 @@
 // value is found exactly with a two-level radix histogram (11 + 5 bits) in two streaming reads,
 // followed by one streaming read that emits the boolean mask.  HBM-bound: 5 B per score.
 //
-// Workspace layout (uint32 words):  [0,2048) hist_hi   [2048,2080) hist_lo   [2080,2084) spare
+// Workspace layout (uint32 words):  [0,2048) hist_hi   [2048,2080) hist_lo   [2080] picked top bin   [2081] 16-bit key of the
+// threshold   [2082,2084) residual rank inside the top bin (uint64)
 #include "kvz_common.h"
 
 namespace kvz {
@@ -113,14 +114,30 @@ __device__ static inline void find_bin_desc(const uint32_t* hist, uint64_t idx, 
 }
 
 // ---- pass 2: histogram of the low 5 bits inside the selected top bin -----------------------
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores,
-                                                                    int64_t n, uint64_t idx,
-                                                                    const uint32_t* __restrict__ hist_hi,
-                                                                    uint32_t* __restrict__ hist_lo) {
-    __shared__ uint32_t ll[LO_BINS];
+// one block: locate the top bin that contains rank idx (the per-block search used to cost more than the streaming)
+__global__ __launch_bounds__(SEL_THREADS) void select_pick_hi_kernel(const uint32_t* __restrict__ hist_hi, uint64_t idx,
+                                                                    uint32_t* __restrict__ picked) {
     uint32_t bin;
     uint64_t rank, above;
     find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
+    if (threadIdx.x == 0) {
+        picked[0] = bin;
+        *reinterpret_cast<uint64_t*>(picked + 2) = rank;
+    }
+}
+__global__ __launch_bounds__(SEL_THREADS) void select_pick_lo_kernel(const uint32_t* __restrict__ hist_lo,
+                                                                    uint32_t* __restrict__ picked) {
+    uint32_t lo;
+    uint64_t rank2, above2;
+    find_bin_desc<LO_BINS>(hist_lo, *reinterpret_cast<const uint64_t*>(picked + 2), &lo, &rank2, &above2);
+    if (threadIdx.x == 0) picked[1] = (picked[0] << 5) | lo;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores,
+                                                                    int64_t n, const uint32_t* __restrict__ picked,
+                                                                    uint32_t* __restrict__ hist_lo) {
+    __shared__ uint32_t ll[LO_BINS];
+    const uint32_t bin = picked[0];
     if (threadIdx.x < LO_BINS) ll[threadIdx.x] = 0;
     __syncthreads();
 
@@ -154,15 +171,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
 // grid = (blocks_per_row, rows) when row_counts != nullptr, each block covering a slice of ONE row;
 // otherwise rows == 1 and row_len == n.
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
-    const uint16_t* __restrict__ scores, int64_t row_len, uint64_t idx, int dtype,
-    const uint32_t* __restrict__ hist_hi, const uint32_t* __restrict__ hist_lo,
+    const uint16_t* __restrict__ scores, int64_t row_len, int dtype, const uint32_t* __restrict__ picked,
     uint8_t* __restrict__ valid_out, int32_t* __restrict__ row_counts, float* __restrict__ thres_dev,
     unsigned long long* __restrict__ kept_dev) {
-    uint32_t bin, lo;
-    uint64_t rank, above, rank2, above2;
-    find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
-    find_bin_desc<LO_BINS>(hist_lo, rank, &lo, &rank2, &above2);
-    const uint32_t tkey = (bin << 5) | lo;
+    const uint32_t tkey = picked[1];
     const uint32_t tbits = order_key16_inv(tkey);
     const float thres = half_bits_to_float(tbits, dtype);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *thres_dev = thres;
@@ -385,26 +397,27 @@ extern "C" int kvz_select_threshold(const void* scores, int64_t n, double ratio,
 
     const int64_t nvec = (n + 7) >> 3;
     int blocks = (int)((nvec + SEL_THREADS - 1) / SEL_THREADS);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;  // 2 per CU: every block flushes its non-empty bins with global atomics
     if (blocks < 1) blocks = 1;
+    uint32_t* picked = hist_lo + LO_BINS;
     const uint16_t* s16 = reinterpret_cast<const uint16_t*>(scores);
     ProfScope ps("select", stream);  // the three streaming passes
     hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, hist_hi);
     KVZ_CHECK_LAUNCH("select_hist_hi_kernel");
-    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, (uint64_t)idx,
-                       hist_hi, hist_lo);
+    hipLaunchKernelGGL(select_pick_hi_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, hist_hi, (uint64_t)idx, picked);
+    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, picked, hist_lo);
     KVZ_CHECK_LAUNCH("select_hist_lo_kernel");
+    hipLaunchKernelGGL(select_pick_lo_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, hist_lo, picked);
 
     // rows whose start is not 16-byte aligned take the scalar path inside the kernel (row_len % 8 != 0)
     const int64_t per_row_vec = ((row_len & 7) == 0) ? (row_len >> 3) : row_len;
     int bx = (int)((per_row_vec + SEL_THREADS - 1) / SEL_THREADS);
-    int max_bx = (int)(4096 / rows);
+    int max_bx = (int)(1024 / rows);
     if (max_bx < 1) max_bx = 1;
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(select_emit_kernel, dim3(bx, (unsigned)rows), dim3(SEL_THREADS), 0, stream, s16, row_len,
-                       (uint64_t)idx, dtype, hist_hi, hist_lo, valid_out, row_counts, thres_dev,
-                       reinterpret_cast<unsigned long long*>(kept_dev));
+    hipLaunchKernelGGL(select_emit_kernel, dim3(bx, (unsigned)rows), dim3(SEL_THREADS), 0, stream, s16, row_len, dtype,
+                       picked, valid_out, row_counts, thres_dev, reinterpret_cast<unsigned long long*>(kept_dev));
     KVZ_CHECK_LAUNCH("select_emit_kernel");
     return KVZ_OK;
 }
