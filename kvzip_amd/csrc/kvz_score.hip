@@ -204,7 +204,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void score_rowstat_kernel(ScoreAr
     float m_run = -INFINITY, ml2_run = 0.f, l_run = 0.f;
     const int diag0 = a.sink + a.m;  // first key that can be masked for some row
 
-    // one 128-key tile = 4 blocks of 32 keys; MASK = tile straddles / lies beyond the causal diagonal
     // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use, so
     // that the matrix chain never waits for LDS latency (sched_barrier pins the order: the compiler would otherwise
     // sink every ds_read next to its MFMA and serialise read latency + MFMA eight times per block)
@@ -213,12 +212,54 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void score_rowstat_kernel(ScoreAr
         for (int kk = 0; kk < C::KK; ++kk)
             fr[kk] = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
     };
-    auto tile_body = [&](const char* buf, int t, auto mask_tag) {
+    // rounding chain + online softmax of one 32-key block whose first key is k0; MASK = per-logit causal test
+    auto epilogue = [&](const f16v& acc, int k0, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        T x[16];
+        const int rel = limit - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            T v = round_chain_h<T, FAST>(acc[i], a.c, a.rcp);
+            if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : (T)(-INFINITY);
+            x[i] = v;
+        }
+        const float tmax = max16<T>(x);
+        if (tmax > m_run) {  // new running maximum: rescale the partial sum
+            const float ml2_new = tmax * L2E;
+            l_run *= __builtin_amdgcn_exp2f(ml2_run - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
+            m_run = tmax;
+            ml2_run = ml2_new;
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i], L2E, -ml2_run));
+            ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i + 1], L2E, -ml2_run));
+        }
+        l_run += ps0 + ps1;  // (masked keys: x = -inf -> exp2(-inf) = 0)
+    };
+    // causal limits of this wave's 32 rows (wave-uniform): a 32-key block is fully visible to the wave if its last key
+    // <= wmin, fully masked if its first key > wmax; only the blocks in between need the per-logit test
+    int wmin = limit, wmax = limit;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        wmin = min(wmin, __shfl_xor(wmin, o, 64));
+        wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    }
+    wmin = __builtin_amdgcn_readfirstlane(wmin);
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    // one 128-key tile = 4 blocks of 32 keys; DIAG = tile straddles / lies beyond the causal diagonal or the key range
+    auto tile_body = [&](const char* buf, int t, auto diag_tag) {
+        constexpr bool DIAG = decltype(diag_tag)::value;
         u32x4 fr[C::KK];
         load_frags(fr, buf, 0);
 #pragma unroll
         for (int kb = 0; kb < SC_TILE / 32; ++kb) {
+            const int k0 = t * SC_TILE + kb * 32;
+            if (DIAG && k0 > wmax) {  // nothing of this block is visible to any row of the wave
+                if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
+                continue;
+            }
             f16v acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -227,28 +268,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void score_rowstat_kernel(ScoreAr
             for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kk]), bq[kk], acc);
             if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
             __builtin_amdgcn_sched_barrier(0);
-            T x[16];
-            const int rel = limit - (t * SC_TILE + kb * 32 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                T v = round_chain_h<T, FAST>(acc[i], a.c, a.rcp);
-                if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : (T)(-INFINITY);
-                x[i] = v;
-            }
-            const float tmax = max16<T>(x);
-            if (tmax > m_run) {  // new running maximum: rescale the partial sum
-                const float ml2_new = tmax * L2E;
-                l_run *= __builtin_amdgcn_exp2f(ml2_run - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
-                m_run = tmax;
-                ml2_run = ml2_new;
-            }
-            float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i], L2E, -ml2_run));
-                ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i + 1], L2E, -ml2_run));
-            }
-            l_run += ps0 + ps1;  // (all-masked so far: x = -inf -> exp2(-inf) = 0)
+            if (DIAG && k0 + 31 > wmin) epilogue(acc, k0, std::true_type{});
+            else epilogue(acc, k0, std::false_type{});
         }
     };
 
