@@ -60,6 +60,7 @@ struct ScoreArgs {
     void* out;           // [Hkv, m] half
     int64_t out_head_stride;
     int row_splits;      // pass B
+    int n_kv_heads;
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
 };
@@ -324,14 +325,21 @@ __global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArg
     __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
     float2* lstat = reinterpret_cast<float2*>(lds + 2 * C::TILE_BYTES);  // [2][128]
 
-    const int h = blockIdx.z;
+    // XCD-aware block order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The blocks that stream the SAME
+    // query-row tiles (same row slice and head, different ctx-key tile) get ids that are congruent mod 8 whenever
+    // row_splits*Hkv is a multiple of 8, so each query tile is fetched into ONE L2 instead of eight.
+    const int SH = a.row_splits * a.n_kv_heads;
+    const int bj = blockIdx.x % SH;            // (row slice, head)
+    const int ctile = blockIdx.x / SH;         // ctx-key tile
+    const int ysplit = bj % a.row_splits;
+    const int h = bj / a.row_splits;
     const int R = a.G * a.q_len;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
     // stationary operand: 32 ctx keys per wave (B operand)
-    const int j = blockIdx.x * SC_COLS + wave * 32 + l31;
+    const int j = ctile * SC_COLS + wave * 32 + l31;
     const bool jvalid = j < a.m;
     v8 bk[C::KK];
     {
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArg
     // this block's slice of the query rows (tiles of 128); the host picks row_splits so that no slice is empty
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
     const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
-    const int t_begin = blockIdx.y * per;
+    const int t_begin = ysplit * per;
     const int t_end = min(total_tiles, t_begin + per);
 
     const char* qbase = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * a.q_head_stride * 2;
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArg
         }
     }
     best = fmaxf(best, __shfl_xor(best, 32, 64));
-    if (half == 0 && jvalid) a.colpart[((int64_t)blockIdx.y * gridDim.z + h) * a.m + j] = best;
+    if (half == 0 && jvalid) a.colpart[((int64_t)ysplit * a.n_kv_heads + h) * a.m + j] = best;
 }
 
 template <typename T>
@@ -528,9 +536,10 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
     const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
+    a.n_kv_heads = Hkv;
     {
         ProfScope ps("score_colmax", stream);
-        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles, a.row_splits, Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
