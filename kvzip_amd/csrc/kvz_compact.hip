@@ -163,7 +163,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_gather_kernel(CompactArgs 
     constexpr int RPI = CP_THREADS / LPR;  // rows per block-iteration
     const int rsub = threadIdx.x / LPR;
     const int coff = (threadIdx.x % LPR) * 16;
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = 8;
     for (int j0 = 0; j0 < total; j0 += RPI * UNROLL) {
         u32x4 kv[UNROLL], vv[UNROLL];
 #pragma unroll
@@ -171,8 +171,9 @@ __global__ __launch_bounds__(CP_THREADS) void compact_gather_kernel(CompactArgs 
             const int j = j0 + u * RPI + rsub;
             if (j < total) {
                 const int64_t so = (int64_t)list[j] * a.row_bytes + coff;
-                kv[u] = *reinterpret_cast<const u32x4*>(ksrc + so);
-                vv[u] = *reinterpret_cast<const u32x4*>(vsrc + so);
+                // streamed exactly once: non-temporal, do not displace anything useful from L2 / MALL
+                kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ksrc + so));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vsrc + so));
             }
         }
 #pragma unroll
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_gather_kernel(CompactArgs 
             const int j = j0 + u * RPI + rsub;
             if (j < total) {
                 const int64_t dof = (int64_t)j * a.row_bytes + coff;
-                *reinterpret_cast<u32x4*>(kdst + dof) = kv[u];
-                *reinterpret_cast<u32x4*>(vdst + dof) = vv[u];
+                __builtin_nontemporal_store(kv[u], reinterpret_cast<u32x4*>(kdst + dof));
+                __builtin_nontemporal_store(vv[u], reinterpret_cast<u32x4*>(vdst + dof));
             }
         }
     }
