@@ -212,6 +212,12 @@ class ModelKVzip:
             kv.prefill_ids = torch.cat([kv.prefill_ids, input_ids, a_ids], dim=1)
         return a_ids if return_ids else self.decode(a_ids)
 
+    def head_score(self, kv) -> torch.Tensor:
+        """Per-(layer, KV head) maximum score ``[L, Hkv]`` — what the reference saves with ``--save_head_score``
+        (test.py:22-25) for context-independent, head-level eviction."""
+        score = kv._stacked_score(kv.score)
+        return score.reshape(score.shape[0], score.shape[-2], score.shape[-1]).amax(-1)
+
     @torch.inference_mode()
     def _prob(self, input_ids: torch.Tensor, kv=None, device: str = "cuda") -> torch.Tensor:
         """Next-token probabilities (reference model/wrapper.py:286-306)."""
