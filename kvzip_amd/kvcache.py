@@ -329,10 +329,15 @@ class EvictCache(_CacheBase):
         """Variable-length attention over the pruned cache: what the reference gets from
         ``flash_attn_varlen_func`` (attention/attn.py:61-71).  Returns ``[Hkv*q_len, G, D]``."""
         dim = query_states.shape[-1]
-        need = ops._lib.load().kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, info["max_len_q"],
-                                                               dim, info["max_len_k"])
-        if self._attn_ws is None or self._attn_ws.numel() < need:
-            self._attn_ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=query_states.device)
+        key = getattr(self, "_attn_ws_key", None)
+        if self._attn_ws is None or key is None or key[0] != info["max_len_q"] or info["max_len_k"] > key[1]:
+            # size the scratch for this query length and some growth of the keys; re-queried only when outgrown
+            cap = info["max_len_k"] + 4096
+            lib = ops._lib.load()
+            need = max(lib.kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, info["max_len_q"], dim, n)
+                       for n in (info["max_len_k"], cap))
+            self._attn_ws = torch.empty(2 * int(need) + 256, dtype=torch.uint8, device=query_states.device)
+            self._attn_ws_key = (info["max_len_q"], cap)
         return ops.varlen_attn(query_states, key_states.view(-1, dim), value_states.view(-1, dim), info["k_start"],
                                info["k_len"], info["max_len_q"], info["max_len_k"], causal=causal,
                                softmax_scale=softmax_scale, workspace=self._attn_ws,

@@ -254,8 +254,8 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
     out = torch.empty_like(q)
-    need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, int(max_len_k))
-    if workspace is None or workspace.numel() < need:
+    if workspace is None:  # (a caller-provided workspace is validated by the library itself: KVZ_EWORKSPACE)
+        need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, int(max_len_k))
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
     rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(),
                              int(k_len_offset), Hkv, G,
