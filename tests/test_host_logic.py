@@ -1,0 +1,123 @@
+"""CPU: host-side logic of the drop-in classes that does not need a kernel — dense cache bookkeeping, score buffer
+management, scoring-chunk construction, sharding — mirrors of reference model/wrapper.py:18-37,197-221 and
+attention/kvcache.py:41-121, attention/score.py:25-34."""
+import types
+
+import pytest
+import torch
+
+import kvzip_oracle as orc
+from kvzip_amd.kvcache import EvictCache, RetainCache
+from kvzip_amd.wrapper import ModelKVzip, chunk_fn
+from kvzip_amd.template import template
+
+
+def _cfg(L=2, H=4, Hkv=2):
+    return types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+
+
+@pytest.mark.parametrize("cls", [EvictCache, RetainCache])
+def test_dense_update_slice_get_seq_length(cls):
+    """update appends in place (amortised growth), slice drops the query/answer rows, _seen_tokens is the logical length."""
+    kv = cls(_cfg(), (3, 13), device="cpu", dtype=torch.float16, reserve=4, verbose=False)
+    assert kv.get_seq_length() == 0 and kv.sink == 3 and kv.ctx_len == 10 and not kv.pruned and not kv.get_score
+    g = torch.Generator().manual_seed(0)
+    parts = [[torch.randn(1, 2, t, 8, generator=g).half() for t in (13, 5, 9)] for _ in range(2)]
+    for step in range(3):
+        for l in range(2):
+            K, V = kv.update(parts[l][step], parts[l][step] * 2, l)
+            want = torch.cat(parts[l][:step + 1], dim=2)
+            assert torch.equal(K, want) and torch.equal(V, want * 2)  # survives two re-allocations (reserve = 4)
+    assert kv.get_seq_length() == 27 and kv._seen_tokens == 27
+    kv.slice(13)
+    assert kv.get_seq_length() == 13 and kv.key_cache[1].shape == (1, 2, 13, 8)
+    assert torch.equal(kv.key_cache[0], parts[0][0])
+    # a later update continues right after the kept rows
+    K, _ = kv.update(parts[0][1], parts[0][1], 0)
+    assert torch.equal(K, torch.cat([parts[0][0], parts[0][1]], dim=2))
+    assert kv._mem() == 0.0
+
+
+def test_get_valid_pads_sink_and_tail():
+    kv = EvictCache(_cfg(L=1), (2, 7), device="cpu", dtype=torch.float16, verbose=False)
+    kv.valid = torch.tensor([[[[1, 0, 0, 1, 1], [0, 0, 0, 0, 1]]]], dtype=torch.bool)
+    full = kv._get_valid(0, 10)
+    assert full.shape == (1, 2, 10)
+    assert full[0, 0].tolist() == [True, True, True, False, False, True, True, True, True, True]
+    assert torch.equal(full, orc.get_valid(kv.valid[0], 2, 10))
+
+
+def test_score_buffer_bookkeeping():
+    """init_score / _update_score keep L views into one [L,1,Hkv,N] buffer; _stacked_score returns it without a copy."""
+    kv = EvictCache(_cfg(L=2), (1, 9), device="cpu", dtype=torch.float16, verbose=False)
+    kv.init_score()
+    assert kv.get_score and len(kv.score) == 2 and kv.score[0].shape == (1, 2, 0)
+    a = [torch.rand(1, 2, 5).half(), torch.rand(1, 2, 3).half()]
+    for l in range(2):
+        for blk in a:
+            kv._update_score(l, blk)
+    for l in range(2):
+        assert kv.score[l].shape == (1, 2, 8) and torch.equal(kv.score[l], torch.cat(a, dim=-1))
+    stacked = kv._stacked_score(kv.score)
+    assert stacked.data_ptr() == kv._score_buf.data_ptr() and stacked.shape == (2, 1, 2, 8)
+    # scores assigned from outside (head-level tensor or a list of foreign tensors) are stacked / passed through
+    foreign = [torch.rand(1, 2, 8).half() for _ in range(2)]
+    assert torch.equal(kv._stacked_score(foreign), torch.stack(foreign))
+    t = torch.rand(2, 1, 2, 8).half()
+    assert kv._stacked_score(t) is t
+    # capacity growth when more scores arrive than ctx_len announced
+    kv._update_score(0, torch.rand(1, 2, 4).half())
+    assert kv.score[0].shape[-1] == 12 and torch.equal(kv.score[1], torch.cat(a, dim=-1))
+
+
+def test_chunk_fn_matches_reference_chunking():
+    ids = torch.arange(4500).view(1, -1)
+    chunks = chunk_fn(ids, 2000)
+    assert [c.shape[1] for c in chunks] == [2000, 2000, 500]
+    assert torch.equal(torch.cat(chunks, dim=1), ids)
+    assert len(chunk_fn(ids[:, :2000], 2000)) == 1 and len(chunk_fn(ids[:, :2001], 2000)) == 2
+
+
+def test_self_task_builds_repeat_prompts():
+    """(chunk ids, repeat prompt ++ postfix ++ chunk ids); later chunks quote the last 8 tokens of the previous chunk
+    (reference model/wrapper.py:197-221)."""
+    m = ModelKVzip.__new__(ModelKVzip)  # no model needed for the prompt construction
+    m.device = torch.device("cpu")
+    m.postfix_ids = torch.tensor([[900, 901]])
+    first, later = torch.tensor([[1, 2, 3]]), torch.tensor([[4, 5, 6, 7]])
+    ctx = torch.arange(100, 100 + 250).view(1, -1)
+    out = m.self_task(ctx, chunk_size=100, prev_postfix_size=8, repeat_prompt_ids=(first, later))
+    assert len(out) == 3
+    a0, r0 = out[0]
+    assert torch.equal(a0, ctx[:, :100]) and torch.equal(r0, torch.cat([first, m.postfix_ids, a0], dim=1))
+    a1, r1 = out[1]
+    assert torch.equal(r1, torch.cat([later, ctx[:, 92:100], m.postfix_ids, a1], dim=1))
+    a2, r2 = out[2]
+    assert a2.shape[1] == 50 and torch.equal(r2[:, 4:12], ctx[:, 192:200])
+    # repeat prompt overhead: q_len - m = len(prompt) + len(postfix) (+ 8 quoted tokens for later chunks)
+    assert r0.shape[1] - 100 == 5 and r1.shape[1] - 100 == 14
+
+
+def test_template_strings():
+    for name in ("Qwen2.5-7B-Instruct-1M", "Llama-3.1-8B-Instruct", "Qwen3-8B", "tiny"):
+        prefix, postfix = template(name, "qa")
+        assert isinstance(prefix, str) and isinstance(postfix, str)
+    assert "<|im_start|>" in template("Qwen2.5-7B", "qa")[0]
+    assert "<|start_header_id|>" in template("Llama-3.1-8B", "qa")[0]
+
+
+def test_unsupported_kv_types_are_refused():
+    m = ModelKVzip.__new__(ModelKVzip)
+    m.kv_type, m.model, m.cache_kwargs = "int4static", None, {}
+    with pytest.raises(NotImplementedError):
+        m._init_kv()
+
+
+def test_product_path_fails_loudly_without_a_device():
+    """No CPU fallback: handing CPU tensors to a kernel wrapper raises instead of computing something else."""
+    from kvzip_amd import ops
+    from kvzip_amd._lib import KvzError
+    with pytest.raises(KvzError):
+        ops.select_threshold(torch.rand(1, 1, 1, 16).half(), 0.3)
+    with pytest.raises((KvzError, AssertionError)):
+        ops.score_chunk(torch.rand(1, 2, 4, 64).half(), torch.rand(1, 1, 20, 64).half(), 0, 0, 8)
