@@ -11,11 +11,14 @@
 //
 // x follows the reference's rounding chain exactly:  x = half( float(half(q.k [fp32 accumulate])) / float(sqrt(D)) ).
 //
-// Tiling (both passes): the operand whose index is reduced over is STREAMED through LDS in 128-row tiles
-// and used as the MFMA A operand (rows of the 32x32 result live in registers, so the reduction is
-// lane-local); the other operand is STATIONARY in registers as the B operand (32 columns per wave,
-// one column per lane).  LDS tiles are XOR-swizzled on 16-byte chunks so that ds_read_b128 fragment
-// reads are bank-conflict free.  Bound: MFMA co-limited by the VALU rounding chain.
+// Tiling (both passes): one operand is STREAMED through LDS in 128-row tiles, the other is STATIONARY in
+// registers (32 rows per wave).  In both passes the QUERY ROW is the column of the 32x32 MFMA result, i.e.
+// one query row per lane: its softmax statistics (pass A: running max / sum, pass B: m_r and log l_r) are
+// per-lane scalars and the 16 accumulator registers of a lane are 16 different keys.  Pass A streams keys
+// (reduction over keys = over registers, lane-local); pass B streams query rows and keeps 16 running
+// per-key maxima per lane that are reduced across lanes once at the end.  LDS tiles are XOR-swizzled on
+// 16-byte chunks so that ds_read_b128 fragment reads are bank-conflict free.
+// Bound: VALU issue of the rounding chain (MFMA and VALU do not overlap on a SIMD).
 #include "kvz_common.h"
 
 #include <math.h>
@@ -41,20 +44,20 @@ template <> struct Mfma32<__bf16> {
 };
 
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (2 x 32 KiB LDS buffers per block -> 2 blocks per CU)
-// pass A: 4 waves / block, 2 waves per SIMD, up to 256 VGPRs: deep register prefetch of the A fragments
-// pass B: 8 waves / block, 4 waves per SIMD, <= 128 VGPRs
-constexpr int PA_WAVES = 4, PB_WAVES = 8;
+constexpr int PB_WAVES = 4;
 #ifndef KVZ_KSPLIT_TILES
-#define KVZ_KSPLIT_TILES 8
+#define KVZ_KSPLIT_TILES 4
 #endif
-constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;  // pass A: key tiles per block (load balance under the causal mask)
+constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;
+constexpr int SC_PERSISTENT_BLOCKS = 256;  // pass A: one persistent block per CU  // pass A: key tiles per block (load balance under the causal mask)
 
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
     const void* k;       // [Hkv, klen, D]
     int64_t q_head_stride, k_head_stride;  // elements
     int klen, sink, start, m, q_len, G;
-    float2* stats;       // [key_splits, Hkv, G*q_len]  partial (m_r, l'_r) of each key slice (l' relative to fl(m*log2e))
+    float2* stats;       // [key_splits, Hkv, stats_stride]  partial (m_r, l'_r) of each key slice (l' relative to fl(m*log2e))
+    int stats_stride;    // G*q_len rounded up to a multiple of SC_TILE; the padding rows hold (+inf, 0) after the merge
     int key_splits;      // pass A: slices of SC_KSPLIT_TILES key tiles
     float* colpart;      // [row_splits, Hkv, m]  per-slice column maxima of the log-softmax
     void* out;           // [Hkv, m] half
@@ -103,6 +106,95 @@ __device__ static inline float max16(const T (&hx)[16]) {
     }
 }
 
+// ---- packed form of the chain: 16 accumulators -> 8 registers holding two 16-bit results each (lo = even, hi = odd) ----
+// fp16 with the exact reciprocal: v_cvt_pk_f16_f32 (first rounding, two values per instruction) followed by
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp32 product of the 16-bit value and rcp, rounded once to fp16, in place).
+// The mix instructions (and the packed maximum tree of pass A) are written as ONE inline-assembly block per 32x32
+// result: left to instruction selection, the second rounding is emitted twice (packed for the maximum, scalar for
+// the exponent) and every packed maximum gets a canonicalising copy - 8.2 instead of 4.6 VALU instructions per logit.
+// Hazards: the MFMA -> VALU wait states are on the compiler-visible conversions; inside the block every consumer is
+// at least one instruction behind its producer (gfx950 needs one wait state after a 16-bit-destination / packed
+// producer), and the block starts and ends with s_nop 0 for the instructions the compiler places around it.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <typename T> __device__ static inline uint32_t bits16(T v) {
+    uint16_t b;
+    __builtin_memcpy(&b, &v, 2);
+    return b;
+}
+template <typename T> __device__ static inline float pair_lo(uint32_t p) {
+    if constexpr (std::is_same<T, _Float16>::value) return (float)__builtin_bit_cast(h2v, p)[0];
+    else return __builtin_bit_cast(float, p << 16);
+}
+template <typename T> __device__ static inline float pair_hi(uint32_t p) {
+    if constexpr (std::is_same<T, _Float16>::value) return (float)__builtin_bit_cast(h2v, p)[1];
+    else return __builtin_bit_cast(float, p & 0xffff0000u);
+}
+// float(16-bit half HI of p) + addend, one rounding (fp16: v_fma_mix_f32 reads the half directly; written as assembly
+// because fma(x, 1, y) is canonicalised to an add with a separate conversion)
+template <typename T, int HI> __device__ static inline float pair_sub(uint32_t p, float neg_m) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        float r;
+        if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(neg_m));
+        else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(neg_m));
+        return r;
+    } else {
+        return (HI ? pair_hi<T>(p) : pair_lo<T>(p)) + neg_m;
+    }
+}
+#define KVZ_MIXLO(i) "v_fma_mixlo_f16 %" #i ", %" #i ", %[r], 0 op_sel_hi:[1,0,0]\n\t"
+#define KVZ_MIXHI(i) "v_fma_mixhi_f16 %" #i ", %" #i ", %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define KVZ_MIX_ALL                                                                                                   \
+    "s_nop 0\n\t" KVZ_MIXLO(0) KVZ_MIXLO(1) KVZ_MIXLO(2) KVZ_MIXLO(3) KVZ_MIXLO(4) KVZ_MIXLO(5) KVZ_MIXLO(6) KVZ_MIXLO(7) \
+        KVZ_MIXHI(0) KVZ_MIXHI(1) KVZ_MIXHI(2) KVZ_MIXHI(3) KVZ_MIXHI(4) KVZ_MIXHI(5) KVZ_MIXHI(6) KVZ_MIXHI(7)
+// xp <- chain of the 16 accumulators; returns the maximum of the 16 results when WITH_MAX (else 0)
+template <typename T, bool FAST, bool WITH_MAX>
+__device__ static inline float chain_block(const float (&acc)[16], uint32_t (&xp)[8], float c, float rcp) {
+    if constexpr (std::is_same<T, _Float16>::value && FAST) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            xp[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{acc[2 * p], acc[2 * p + 1]}, h2v));
+        if constexpr (WITH_MAX) {
+            uint32_t m0, m1, m2, m3;
+            asm(KVZ_MIX_ALL
+                "v_pk_max_f16 %[m0], %0, %1\n\t"
+                "v_pk_max_f16 %[m1], %2, %3\n\t"
+                "v_pk_max_f16 %[m2], %4, %5\n\t"
+                "v_pk_max_f16 %[m3], %6, %7\n\t"
+                "v_pk_max_f16 %[m0], %[m0], %[m1]\n\t"
+                "v_pk_max_f16 %[m2], %[m2], %[m3]\n\t"
+                "s_nop 0\n\t"
+                "v_pk_max_f16 %[m0], %[m0], %[m2]\n\t"
+                "s_nop 0"
+                : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]), "+v"(xp[4]), "+v"(xp[5]), "+v"(xp[6]), "+v"(xp[7]),
+                  [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3)
+                : [r] "s"(rcp));
+            const h2v m = __builtin_bit_cast(h2v, m0);
+            return fmaxf((float)m[0], (float)m[1]);
+        } else {
+            asm(KVZ_MIX_ALL "s_nop 0"
+                : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]), "+v"(xp[4]), "+v"(xp[5]), "+v"(xp[6]), "+v"(xp[7])
+                : [r] "s"(rcp));
+            return 0.f;
+        }
+    } else {
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const T x0 = round_chain_h<T, FAST>(acc[2 * p], c, rcp), x1 = round_chain_h<T, FAST>(acc[2 * p + 1], c, rcp);
+            xp[p] = bits16(x0) | (bits16(x1) << 16);
+            if (WITH_MAX) {
+                m0 = fmaxf(m0, (float)x0);
+                m1 = fmaxf(m1, (float)x1);
+            }
+        }
+        return fmaxf(m0, m1);
+    }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int D> struct ScoreCfg {
     static constexpr int ROW_BYTES = D * 2;
     static constexpr int CPR = ROW_BYTES / 16;                       // 16-byte chunks per row
@@ -115,14 +207,49 @@ template <int D> struct ScoreCfg {
     }
 };
 
+// ---- fragment reads: 8 (D=128) / 4 (D=64) ds_read_b128 per 32-row block ------------------------------------------
+template <int D> struct FragAddr {
+    static constexpr int KK = D / 16;
+    uint32_t a[KK];  // LDS byte address of this lane's chunk kk of row (lane & 31) in a tile at LDS offset 0
+    __device__ inline void init(const char* lds_base, int l31, int half) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            a[kk] = (uint32_t)(uintptr_t)(lptr_t)(lds_base) + (uint32_t)ScoreCfg<D>::lds_off(l31, kk * 2 + half);
+    }
+};
+template <int D>
+__device__ static inline void frag_load(u32x4 (&fr)[D / 16], const FragAddr<D>& fa, int byte_off /* compile-time after unrolling */) {
+    typedef const __attribute__((address_space(3))) u32x4* lp;
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) fr[kk] = *(lp)(uintptr_t)(fa.a[kk] + byte_off);
+}
+
 // ---- staging: one 128-row tile, HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR round trip) ---------
 // One wave-instruction writes 1 KiB = 64 lanes x 16 B LINEARLY (wave-uniform base + lane*16).  The XOR swizzle of
 // the tile is therefore applied on the SOURCE side: LDS position p of a row receives global chunk p ^ f(row), and
 // fragment reads use lds_off(row, chunk) = position chunk ^ f(row) (same involution on both sides).
 // rowptr clamps out-of-range rows to a valid row: loads are UNCONDITIONAL; out-of-range rows are neutralised
 // downstream (causal limit in pass A, m = +inf statistics in pass B).
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+//
+// The LDS-DMA instruction is issued from inline assembly.  Through the builtin, the compiler cannot prove that a
+// ds_read of one tile buffer does not alias the DMA write that is in flight into the OTHER buffer and puts
+// s_waitcnt vmcnt(0) in front of the first fragment read after every staging call - the full global latency, once
+// per tile (20 % of pass A in an in-kernel trace).  Ordering between the DMA and the fragment reads is by
+// stage_wait() + the block barrier, exactly as designed.  (The opposite choice - builtin DMA, assembly ds_reads -
+// is NOT safe: register copies the compiler inserts between an assembly read and its s_waitcnt read stale data.)
+// M0 (LDS base of the DMA) is not used by anything else in these kernels.
+__device__ static inline void lds_dma16(const void* gsrc, const char* lds_dst /* wave-uniform */) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)(lds_dst));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");
+}
+// all LDS-DMA of this wave has landed (the compiler does not count the assembly loads: its own vmcnt waits can only
+// become more conservative, never weaker, because the counter retires in order)
+__device__ static inline void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// block barrier without the release/acquire fences of __syncthreads(): the fence makes the compiler wait for vmcnt(0)
+// whenever it has a global load, store or atomic of its own in flight, which (the hardware counter being shared) drains
+// every tile staged ahead.  LDS traffic of this wave is complete (lgkmcnt 0) before the barrier.
+__device__ static inline void block_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int D, int NW, typename RowPtr>
 __device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int wave, int lane) {
     typedef ScoreCfg<D> C;
@@ -137,7 +264,34 @@ __device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int
         const int p = lane % C::CPR;
         const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
         const char* src = rowptr(row0 + row) + chunk * 16;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + ci * 1024), 16, 0, 0);
+        lds_dma16(src, buf + ci * 1024);
+    }
+}
+
+// Fast variant for a tile whose 128 rows are CONSECUTIVE in memory (the common case): the address is a wave-uniform
+// base (SGPRs) plus ONE per-lane byte offset that is the same for every piece, because the swizzle term of a row only
+// depends on (wave, lane) when the piece stride NW*ROWS_PER_INSTR is a multiple of 16 rows.  This removes the per-lane
+// clamp / segment select / 64-bit multiply-add (pass A) and the integer division (pass B) from every staged load.
+template <int D, int NW>
+__device__ static inline uint32_t stage_lane_offset(int wave, int lane) {
+    typedef ScoreCfg<D> C;
+    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+    static_assert((NW * ROWS_PER_INSTR) % 16 == 0, "swizzle must not depend on the piece index");
+    const int row = wave * ROWS_PER_INSTR + lane / C::CPR;
+    const int p = lane % C::CPR;
+    const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
+    return (uint32_t)(row * C::ROW_BYTES + chunk * 16);
+}
+template <int D, int NW>
+__device__ static inline void stage_tile_linear(char* buf, const char* base, uint32_t lane_off, int wave) {
+    typedef ScoreCfg<D> C;
+    constexpr int INSTR = C::TILE_BYTES / 1024;
+    constexpr int PER_WAVE = INSTR / NW;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int ci = i * NW + wave;
+        const char* src = base + (size_t)i * NW * 1024 + lane_off;
+        lds_dma16(src, buf + ci * 1024);
     }
 }
 
@@ -145,169 +299,397 @@ __device__ static inline void stage_tile(char* buf, int row0, RowPtr rowptr, int
 // Online softmax in the exp2 domain: the running pseudo-maximum ml2 = fl(m * log2e) is an fp32 number, every term
 // is exp2(fma(x, log2e, -ml2)) (one rounding), and the common factor 2^(m*log2e - ml2) that this introduces
 // into l is removed exactly at the end (delta = fma(m, log2e, -ml2)).
+//
+// Execution shape (from in-kernel s_memtime traces, per-block Gantt charts and ablations, tools/ablate_score.py):
+//  * one 8-wave block per CU (two waves per SIMD), 32 query rows per wave, 256 rows per key tile: half the L2->LDS
+//    traffic per logit of a 128-row block.  (KVZ_PA_WAVES=4 / KVZ_PA_RG=2 builds the one-wave-per-SIMD variant with two
+//    interleaved matrix chains per wave; a lone wave exposes every latency and is 35 % slower.)
+//  * No global load with a register destination inside the kernel: key tiles AND the query rows of the next item come
+//    in by LDS-DMA issued from assembly.  A load the compiler knows about makes it place s_waitcnt vmcnt(n) wherever
+//    one of the affected registers is touched, and because the hardware counter also holds the DMA, every such wait
+//    drains the tiles staged ahead.  For the same reason the barrier is a bare s_barrier (no fence) and the work
+//    list is STATIC (no atomic queue): block b takes items b, 2G-1-b, 2G+b, ... of a heaviest-first order, which
+//    also removes the 27 % that one-block-per-item launches lost to packing (3.5 rounds of 24-us blocks, the heavy
+//    ones draining alone at the end) and the 2-4 us every block waited for its first tile.
+//  * Latencies are hidden by distance: the DMA of tile p+2 is issued when tile p is handed back, fragment reads run
+//    one 32-key block ahead into a second register set (a prefetch into the registers the chain in flight still
+//    reads stalls the in-order issue), and the hand-over barrier sits right after the LAST matrix chain of a tile
+//    has been issued, not after its epilogue.  The tile stream runs across item boundaries.
+#ifndef KVZ_PA_WAVES
+#define KVZ_PA_WAVES 8
+#define KVZ_PA_RG 1
+#endif
+constexpr int PA_WAVES = KVZ_PA_WAVES;
+constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
+constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
+constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
+
+// keys of the virtual sequence  sink ++ ctx chunk ++ repeat chunk  ->  rows of the cache (slow, per-lane path)
+struct KeyMap {
+    const char* kh;
+    int KT, sink, m, off_ctx, off_rep;
+};
+template <int D, int NW>
+__device__ __attribute__((noinline)) static void stage_keys_gather(char* buf, KeyMap km, int kv0, int wave, int lane) {
+    typedef ScoreCfg<D> C;
+    auto keyptr = [&](int kv) -> const char* {
+        kv = min(kv, km.KT - 1);
+        const int row = kv + (kv < km.sink ? 0 : (kv < km.sink + km.m ? km.off_ctx : km.off_rep));
+        return km.kh + (int64_t)row * C::ROW_BYTES;
+    };
+    stage_tile<D, NW>(buf, kv0, keyptr, wave, lane);
+}
+// 32 query rows (one row group of one wave) -> LDS, same swizzle as a key tile; rows beyond R shadow row R-1
+struct RowMap {
+    const char* qh;  // first query head of the KV head
+    int64_t head_stride_bytes;
+    int q_len, R;
+};
+template <int D>
+__device__ __attribute__((noinline)) static void stage_rows32(char* buf, RowMap rm, int r0, int lane) {
+    typedef ScoreCfg<D> C;
+    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+        const int row = i * ROWS_PER_INSTR + lane / C::CPR;
+        const int p = lane % C::CPR;
+        const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
+        const int r = min(r0 + row, rm.R - 1);
+        const int g = r / rm.q_len;
+        const int qi = r - g * rm.q_len;
+        lds_dma16(rm.qh + g * rm.head_stride_bytes + (int64_t)qi * C::ROW_BYTES + chunk * 16, buf + i * 1024);
+    }
+}
+
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PA_WAVES * 64, 2) void score_rowstat_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_kernel(ScoreArgs a) {
     constexpr int NWAVES = PA_WAVES;
-    constexpr int SC_COLS = NWAVES * 32;  // stationary query rows per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES];
+    constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
+    __shared__ __attribute__((aligned(16))) char lds[PA_NBUF * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
+    char* const qarea = lds + PA_NBUF * C::TILE_BYTES;
     constexpr float L2E = 1.44269504088896340736f;
 
-    const int h = blockIdx.y;
     const int R = a.G * a.q_len;
     const int KT = a.sink + a.m + a.q_len;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-
-    // stationary operand: 32 query rows per wave, one per lane (B operand: col = row index)
-    const int r = blockIdx.x * SC_COLS + wave * 32 + l31;
-    const bool rvalid = r < R;
-    const int rc = min(r, R - 1);  // out-of-range lanes shadow the last row; their result is never stored
-    const int g = rc / a.q_len;
-    const int qi = rc - g * a.q_len;
-    v8 bq[C::KK];
-    {
-        const char* qp = reinterpret_cast<const char*>(a.q) +
-                         (((int64_t)h * a.G + g) * a.q_head_stride + (int64_t)qi * D) * 2 + half * 16;
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk)
-            bq[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(qp + kk * 32));
-    }
-    // key j (virtual index) is visible to query i iff j <= sink + m + i  (reference score.py:67-85)
-    const int limit = a.sink + a.m + qi;
-
-    // block-uniform loop bound: the largest limit of any row in the block; this block owns key tiles [t_lo, t_hi)
-    int kend;
-    {
-        const int r0 = blockIdx.x * SC_COLS;
-        const int r1 = min(R - 1, r0 + SC_COLS - 1);
-        const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
-        kend = min(KT, a.sink + a.m + qmax + 1);
-    }
-    const int ntiles = (kend + SC_TILE - 1) / SC_TILE;
-    // dispatch order follows blockIdx.z: run the LAST key slices (masked, diagonal tiles) first so that the tail of
-    // the launch consists of the cheapest blocks
-    const int zslice = (int)gridDim.z - 1 - (int)blockIdx.z;
-    const int t_lo = zslice * SC_KSPLIT_TILES;
-    const int t_hi = min(ntiles, t_lo + SC_KSPLIT_TILES);
-
-    const char* kh = reinterpret_cast<const char*>(a.k) + (int64_t)h * a.k_head_stride * 2;
+    const int diag0 = a.sink + a.m;  // first key that can be masked for some row
     const int off_ctx = a.start - a.sink;                       // virtual -> cache row, ctx segment
     const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
-    auto keyptr = [&](int kv) -> const char* {
-        kv = min(kv, KT - 1);
-        const int row = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
-        return kh + (int64_t)row * C::ROW_BYTES;
-    };
+    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
 
-    float m_run = -INFINITY, ml2_run = 0.f, l_run = 0.f;
-    const int diag0 = a.sink + a.m;  // first key that can be masked for some row
-
-    // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use, so
-    // that the matrix chain never waits for LDS latency (sched_barrier pins the order: the compiler would otherwise
-    // sink every ds_read next to its MFMA and serialise read latency + MFMA eight times per block)
-    auto load_frags = [&](u32x4 (&fr)[C::KK], const char* buf, int kb) {
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk)
-            fr[kk] = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
+    // ---- work items: index -> (key slice z, row tile rt, head h); z ascending = heaviest (unmasked) slices first ----
+    const int RT = (R + PA_ROWS - 1) / PA_ROWS;
+    const int per_z = RT * a.n_kv_heads;
+    const int nitems = per_z * a.key_splits;
+    struct Item { int k, h, rt, z, t_lo, t_hi; };  // k = position in this block's list; t_lo >= t_hi: none
+    auto decode = [&](int i) __attribute__((always_inline)) -> Item {
+        Item it;
+        it.k = 0;
+        it.z = i / per_z;
+        const int rem = i - it.z * per_z;
+        it.rt = rem / a.n_kv_heads;
+        it.h = rem - it.rt * a.n_kv_heads;
+        // loop bound of the row tile: the largest causal limit of any of its rows
+        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
+        const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
+        const int ntiles = (min(KT, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
+        it.t_lo = it.z * SC_KSPLIT_TILES;
+        it.t_hi = min(ntiles, it.t_lo + SC_KSPLIT_TILES);
+        return it;
     };
-    // rounding chain + online softmax of one 32-key block whose first key is k0; MASK = per-logit causal test
-    auto epilogue = [&](const f16v& acc, int k0, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        T x[16];
-        const int rel = limit - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T v = round_chain_h<T, FAST>(acc[i], a.c, a.rcp);
-            if (MASK) v = ((i & 3) + 8 * (i >> 2) <= rel) ? v : (T)(-INFINITY);
-            x[i] = v;
+    // static snake schedule: the k-th item of block b is k*G + b (k even) or (k+1)*G - 1 - b (k odd); empty items (key
+    // slices beyond the causal limit of their row tile) are skipped
+    const int G_ = gridDim.x;
+    auto item_from = [&](int k) -> Item {  // first non-empty item at list position >= k
+        Item it;
+        it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
+        for (;; ++k) {
+            const int i = (k & 1) ? (k + 1) * G_ - 1 - (int)blockIdx.x : k * G_ + (int)blockIdx.x;
+            if (k * G_ >= nitems) return it;  // whole round beyond the list
+            if (i >= nitems) continue;
+            Item c = decode(i);
+            if (c.t_lo < c.t_hi) {
+                c.k = k;
+                return c;
+            }
         }
-        const float tmax = max16<T>(x);
-        if (tmax > m_run) {  // new running maximum: rescale the partial sum
-            const float ml2_new = tmax * L2E;
-            l_run *= __builtin_amdgcn_exp2f(ml2_run - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
-            m_run = tmax;
-            ml2_run = ml2_new;
+    };
+    auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
+    auto head_keys = [&](int h) -> const char* { return reinterpret_cast<const char*>(a.k) + (int64_t)h * a.k_head_stride * 2; };
+    // stage key tile t of head h into LDS buffer b: linear when its 128 keys lie in one segment (sink / ctx / repeat)
+    auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
+        char* dst = lds + b * C::TILE_BYTES;
+        const char* kh = head_keys(h);
+        const int kv0 = t * SC_TILE, kv1 = kv0 + SC_TILE - 1;
+        int off = 0;
+        bool linear = kv1 < KT;
+        if (kv1 < a.sink) off = 0;
+        else if (kv0 >= a.sink + a.m) off = off_rep;
+        else if (kv0 >= a.sink && kv1 < a.sink + a.m) off = off_ctx;
+        else linear = false;
+        if (linear) stage_tile_linear<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
+        else stage_keys_gather<D, NWAVES>(dst, KeyMap{kh, KT, a.sink, a.m, off_ctx, off_rep}, kv0, wave, lane);
+    };
+    // this wave's 64 query rows of an item -> its private LDS area (two row groups)
+    auto stage_q = [&](const Item& it) __attribute__((always_inline)) {
+        const RowMap rm{reinterpret_cast<const char*>(a.q) + (int64_t)it.h * a.G * a.q_head_stride * 2, a.q_head_stride * 2, a.q_len, R};
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g)
+            stage_rows32<D>(qarea + (wave * PA_RG + g) * QG_BYTES, rm, it.rt * PA_ROWS + (wave * PA_RG + g) * 32, lane);
+    };
+    FragAddr<D> fa0;
+    fa0.init(lds, l31, half);
+    // B operand (one query row per lane) of the two row groups, from the wave's LDS area
+    auto read_q = [&](v8 (&dst)[PA_RG][C::KK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            FragAddr<D> fq;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) fq.a[kk] = fa0.a[kk] + (uint32_t)(PA_NBUF * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
+            u32x4 tmp[C::KK];
+            frag_load<D>(tmp, fq, 0);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) dst[g][kk] = __builtin_bit_cast(v8, tmp[kk]);
+        }
+    };
+    // per-lane row bookkeeping of an item
+    struct Rows { int r[PA_RG], limit[PA_RG]; };
+    auto rows_of = [&](const Item& it) __attribute__((always_inline)) -> Rows {
+        Rows w;
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            w.r[g] = it.rt * PA_ROWS + (wave * PA_RG + g) * 32 + l31;
+            const int rc = min(w.r[g], R - 1);
+            w.limit[g] = a.sink + a.m + rc % a.q_len;  // key j (virtual index) is visible to query i iff j <= sink + m + i  (score.py:67-85)
+        }
+        return w;
+    };
+    // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use
+    auto load_frags = [&](u32x4 (&fr)[C::KK], int b /* runtime buffer */, int kb /* compile-time */) __attribute__((always_inline)) {
+        FragAddr<D> fb;
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) fb.a[kk] = fa0.a[kk] + (uint32_t)(b * C::TILE_BYTES);
+        frag_load<D>(fr, fb, kb * 32 * C::ROW_BYTES);
+    };
+
+    Item cur = item_from(0);
+    if (!valid(cur)) return;
+    Item nxt = item_from(cur.k + 1);
+    // stage cursor: the next tile of the stream that has not been staged yet
+    bool sq_in_next = false, sq_done = false;
+    int sq_t = cur.t_lo;
+    auto sq_stage = [&](int b) __attribute__((always_inline)) {  // stage the cursor's tile into buffer b and advance
+        stage(b, sq_in_next ? nxt.h : cur.h, sq_t);
+        ++sq_t;
+        if (sq_t >= (sq_in_next ? nxt.t_hi : cur.t_hi)) {
+            if (!sq_in_next && valid(nxt)) {
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            } else {
+                sq_done = true;
+            }
+        }
+    };
+    stage_q(cur);
+    sq_stage(0);
+    bool ahead = false;  // the tile after the current one is staged
+    if (!sq_done) {
+        sq_stage(1);
+        ahead = true;
+    }
+    stage_wait();
+    block_barrier();
+    v8 bq[PA_RG][C::KK];
+    read_q(bq);
+    u32x4 fr[2][C::KK];
+    load_frags(fr[0], 0, 0);
+#pragma unroll
+    for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
+    if (valid(nxt)) stage_q(nxt);
+    Rows rows = rows_of(cur);
+
+    int pbuf = 0;  // buffer of the tile being computed
+    int t = cur.t_lo;
+    float m_run[PA_RG], ml2_run[PA_RG], l_run[PA_RG];
+    int wmin[PA_RG], wmax[PA_RG];
+    auto start_item = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            m_run[g] = -INFINITY;
+            ml2_run[g] = 0.f;
+            l_run[g] = 0.f;
+            // causal limits of the group's 32 rows (wave-uniform): a 32-key block is fully visible to the group if its
+            // last key <= wmin, fully masked if its first key > wmax; only the blocks in between need the per-logit test
+            int lo = rows.limit[g], hi = rows.limit[g];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, __shfl_xor(lo, o, 64));
+                hi = max(hi, __shfl_xor(hi, o, 64));
+            }
+            wmin[g] = __builtin_amdgcn_readfirstlane(lo);
+            wmax[g] = __builtin_amdgcn_readfirstlane(hi);
+        }
+    };
+    start_item();
+
+    // rounding chain + online softmax of one 32-key block of row group g whose first key is k0; MASK = per-logit causal test
+    auto epilogue = [&](const f16v& acc, int k0, auto g_tag, auto mask_tag) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value;
+        uint32_t xp[8];
+        float av[16];
+        const int rel = rows.limit[g] - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
+#pragma unroll
+        for (int i = 0; i < 16; ++i)  // -inf survives the chain: half(-inf) = -inf, -inf * rcp = -inf / c = -inf
+            av[i] = (!MASK || (i & 3) + 8 * (i >> 2) <= rel) ? acc[i] : -INFINITY;
+        const float tmax = chain_block<T, FAST, true>(av, xp, a.c, a.rcp);
+        if (__builtin_amdgcn_ballot_w64(tmax > m_run[g]) != 0) {  // wave-uniform branch: rare after the first blocks
+            asm volatile("" ::: "memory");                        // (keeps it a branch: if-conversion costs 16 VALU / block)
+            if (tmax > m_run[g]) {  // new running maximum: rescale the partial sum
+                const float ml2_new = tmax * L2E;
+                l_run[g] *= __builtin_amdgcn_exp2f(ml2_run[g] - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
+                m_run[g] = tmax;
+                ml2_run[g] = ml2_new;
+            }
         }
         float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i], L2E, -ml2_run));
-            ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i + 1], L2E, -ml2_run));
+        for (int p = 0; p < 8; ++p) {
+            ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xp[p]), L2E, -ml2_run[g]));
+            ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xp[p]), L2E, -ml2_run[g]));
         }
-        l_run += ps0 + ps1;  // (masked keys: x = -inf -> exp2(-inf) = 0)
+        l_run[g] += ps0 + ps1;  // (masked keys: x = -inf -> exp2(-inf) = 0)
     };
-    // causal limits of this wave's 32 rows (wave-uniform): a 32-key block is fully visible to the wave if its last key
-    // <= wmin, fully masked if its first key > wmax; only the blocks in between need the per-logit test
-    int wmin = limit, wmax = limit;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        wmin = min(wmin, __shfl_xor(wmin, o, 64));
-        wmax = max(wmax, __shfl_xor(wmax, o, 64));
-    }
-    wmin = __builtin_amdgcn_readfirstlane(wmin);
-    wmax = __builtin_amdgcn_readfirstlane(wmax);
-    // one 128-key tile = 4 blocks of 32 keys; DIAG = tile straddles / lies beyond the causal diagonal or the key range
-    auto tile_body = [&](const char* buf, int t, auto diag_tag) {
+    // hand-over of the current tile's buffer (between its last matrix chains and its last epilogues)
+    bool ahead_next = false, late = false;
+    auto turnover = [&]() __attribute__((always_inline)) {
+        stage_wait();     // my part of everything in flight (the next tile, the next item's query rows) has landed
+        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more
+        if (ahead) {  // normal case: tile p+1 is in the other buffer; refill this one with tile p+2
+            ahead_next = !sq_done;
+            if (!sq_done) sq_stage(pbuf);
+            load_frags(fr[0], pbuf ^ 1, 0);
+        } else {      // the stream was starved (items of a single tile) or ends here: both buffers are free
+            late = !sq_done;
+            if (!sq_done) sq_stage(pbuf ^ 1);
+            ahead_next = !sq_done;
+            if (!sq_done) sq_stage(pbuf);
+        }
+    };
+    // one 128-key tile = 4 blocks of 32 keys x PA_RG row groups; DIAG = tile straddles / lies beyond the causal diagonal
+    auto tile_body = [&](auto diag_tag) __attribute__((always_inline)) {
         constexpr bool DIAG = decltype(diag_tag)::value;
-        u32x4 fr[C::KK];
-        load_frags(fr, buf, 0);
 #pragma unroll
         for (int kb = 0; kb < SC_TILE / 32; ++kb) {
             const int k0 = t * SC_TILE + kb * 32;
-            if (DIAG && k0 > wmax) {  // nothing of this block is visible to any row of the wave
-                if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
-                continue;
+            bool skip[PA_RG];
+            f16v acc[PA_RG];
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g) {
+                skip[g] = DIAG && k0 > wmax[g];  // nothing of this block is visible to any row of the group
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
             }
-            f16v acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             __builtin_amdgcn_sched_barrier(0);
+            // the chains of different row groups are independent and are issued ALTERNATELY
 #pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kk]), bq[kk], acc);
-            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
+            for (int kk = 0; kk < C::KK; ++kk)
+#pragma unroll
+                for (int g = 0; g < PA_RG; ++g)
+                    if (!skip[g]) acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);
+            else turnover();
             __builtin_amdgcn_sched_barrier(0);
-            if (DIAG && k0 + 31 > wmin) epilogue(acc, k0, std::true_type{});
-            else epilogue(acc, k0, std::false_type{});
+            auto epi = [&](auto g_tag) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_tag)::value;
+                if (skip[g]) return;
+                if (DIAG && k0 + 31 > wmin[g]) epilogue(acc[g], k0, g_tag, std::true_type{});
+                else epilogue(acc[g], k0, g_tag, std::false_type{});
+            };
+            epi(std::integral_constant<int, 0>{});
+            if constexpr (PA_RG > 1) epi(std::integral_constant<int, PA_RG - 1>{});
         }
     };
 
-    if (t_lo < t_hi) {
-        stage_tile<D, NWAVES>(lds, t_lo * SC_TILE, keyptr, wave, lane);
-        __syncthreads();
-        for (int t = t_lo; t < t_hi; ++t) {
-            const int cur = (t - t_lo) & 1;
-            const char* buf = lds + cur * C::TILE_BYTES;
-            if (t + 1 < t_hi) stage_tile<D, NWAVES>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, keyptr, wave, lane);
-            if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(buf, t, std::true_type{});   // also covers kv >= KT
-            else tile_body(buf, t, std::false_type{});
-            __syncthreads();  // next tile landed (vmcnt drained) and everybody is done reading this one
+    while (true) {
+        if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(std::true_type{});   // also covers kv >= KT
+        else tile_body(std::false_type{});
+        pbuf ^= 1;
+        ahead = ahead_next;
+        if (late) {  // (rare) the next tile could only be staged at the hand-over: wait for it here
+            stage_wait();
+            block_barrier();
+            load_frags(fr[0], pbuf, 0);
+            late = false;
         }
+        if (++t < cur.t_hi) continue;
+
+        // ---- item finished: partial statistics of this key slice ----
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            // merge the two half-waves (they saw disjoint keys of the same query row)
+            const float m_o = __shfl_xor(m_run[g], 32, 64);
+            const float ml2_o = __shfl_xor(ml2_run[g], 32, 64);
+            const float l_o = __shfl_xor(l_run[g], 32, 64);
+            const float M = fmaxf(m_run[g], m_o);
+            const float ML2 = (m_run[g] >= m_o) ? ml2_run[g] : ml2_o;
+            const float Lp = l_run[g] * __builtin_amdgcn_exp2f(ml2_run[g] - ML2) + l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
+            if (half == 0 && rows.r[g] < R)
+                a.stats[((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + rows.r[g]] = make_float2(M, Lp);
+        }
+        if (!valid(nxt)) break;
+        // ---- switch to the next item: its first tile is in LDS (fragments already prefetched), its query rows landed
+        // before the last hand-over ----
+        cur = nxt;
+        nxt = item_from(cur.k + 1);
+        t = cur.t_lo;
+        rows = rows_of(cur);
+        read_q(bq);
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // rows in registers: the area is free again
+        if (valid(nxt)) stage_q(nxt);
+        if (sq_in_next) {  // the cursor was already inside the item that is now current
+            sq_in_next = false;
+            if (sq_done && valid(nxt)) {
+                sq_done = false;
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            }
+        }
+        start_item();
     }
-    // merge the two half-waves (they saw disjoint keys of the same query row)
-    const float m_o = __shfl_xor(m_run, 32, 64);
-    const float ml2_o = __shfl_xor(ml2_run, 32, 64);
-    const float l_o = __shfl_xor(l_run, 32, 64);
-    const float M = fmaxf(m_run, m_o);
-    const float ML2 = (m_run >= m_o) ? ml2_run : ml2_o;
-    const float Lp = l_run * __builtin_amdgcn_exp2f(ml2_run - ML2) + l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
-    // partial statistics of this key slice (empty slice: m = -inf, l' = 0)
-    if (half == 0 && rvalid) a.stats[((int64_t)zslice * gridDim.y + h) * R + r] = make_float2(M, Lp);
 }
 
 // merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
-// 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).
-__global__ void score_merge_stats_kernel(float2* __restrict__ stats, int key_splits, int64_t rows_total) {
+// 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).  Only the slices below the causal limit of the row's tile exist.
+__global__ void score_merge_stats_kernel(ScoreArgs a, int R, int64_t rows_total) {
     constexpr float L2E = 1.44269504088896340736f;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int SC_COLS = PA_ROWS;
+    float2* __restrict__ stats = a.stats;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [Hkv, stats_stride]
     if (i >= rows_total) return;
+    const int r = (int)(i % a.stats_stride);
+    if (r >= R) {  // padding row: (m = +inf) makes x - m = -inf in pass B, it never wins a maximum
+        stats[i] = make_float2(INFINITY, 0.f);
+        return;
+    }
+    const int r0 = r / SC_COLS * SC_COLS, r1 = min(R - 1, r0 + SC_COLS - 1);
+    const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
+    const int ntiles = (min(a.sink + a.m + a.q_len, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
+    const int slices = min(a.key_splits, (ntiles + SC_KSPLIT_TILES - 1) / SC_KSPLIT_TILES);
     float M = -INFINITY;
-    for (int s = 0; s < key_splits; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
+    for (int s = 0; s < slices; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
     const float ML2 = M * L2E;
     float Lp = 0.f;
-    for (int s = 0; s < key_splits; ++s) {
+    for (int s = 0; s < slices; ++s) {
         const float2 ps = stats[s * rows_total + i];
         Lp += ps.y * __builtin_amdgcn_exp2f(ps.x * L2E - ML2);
     }
@@ -317,13 +699,12 @@ __global__ void score_merge_stats_kernel(float2* __restrict__ stats, int key_spl
 
 // ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
     constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
-    float2* lstat = reinterpret_cast<float2*>(lds + 2 * C::TILE_BYTES);  // [2][128]
+    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES];
 
     // XCD-aware block order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The blocks that stream the SAME
     // query-row tiles (same row slice and head, different ctx-key tile) get ids that are congruent mod 8 whenever
@@ -338,16 +719,15 @@ __global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArg
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
-    // stationary operand: 32 ctx keys per wave (B operand)
-    const int j = ctile * SC_COLS + wave * 32 + l31;
-    const bool jvalid = j < a.m;
-    v8 bk[C::KK];
+    // stationary operand: 32 ctx keys per wave as the A operand (result row = key, 16 keys per lane)
+    const int j0 = ctile * SC_COLS + wave * 32;
+    v8 ak[C::KK];
     {
-        const char* kp = reinterpret_cast<const char*>(a.k) +
-                         ((int64_t)h * a.k_head_stride + (int64_t)(a.start + (jvalid ? j : 0)) * D) * 2 + half * 16;
+        const int j = min(j0 + l31, a.m - 1);
+        const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + j) * D) * 2 + half * 16;
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk)
-            bk[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
+            ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
     }
     // this block's slice of the query rows (tiles of 128); the host picks row_splits so that no slice is empty
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
@@ -362,55 +742,111 @@ __global__ __launch_bounds__(PB_WAVES * 64, 4) void score_colmax_kernel(ScoreArg
         const int qi = r - g * a.q_len;
         return qbase + ((int64_t)g * a.q_head_stride + (int64_t)qi * D) * 2;
     };
-    const float2* stats_h = a.stats + (int64_t)h * R;  // merged (m_r, log l_r)
-    auto load_stat = [&](int t) -> float2 {
-        const int r = t * SC_TILE + (int)(threadIdx.x & (SC_TILE - 1));
-        const float2 v = stats_h[min(r, R - 1)];
-        // rows beyond R get (m = +inf): x - inf = -inf never wins the max
-        return (r < R) ? v : make_float2(INFINITY, 0.f);
+    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
+    // stage query-row tile t: linear when its 128 rows belong to one query head of the group
+    auto stage = [&](char* dst, int t) {
+        const int r0 = t * SC_TILE, r1 = r0 + SC_TILE - 1;
+        const int g0 = r0 / a.q_len;
+        const int qi0 = r0 - g0 * a.q_len;
+        if (r1 < R && qi0 + SC_TILE <= a.q_len)
+            stage_tile_linear<D, NWAVES>(dst, qbase + ((int64_t)g0 * a.q_head_stride + (int64_t)qi0 * D) * 2, lane_off, wave);
+        else
+            stage_tile<D, NWAVES>(dst, r0, rowptr, wave, lane);
+    };
+    // merged statistics (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of a tile; the array is
+    // padded to whole tiles with (+inf, 0), so the loads are unconditional
+    const float2* stats_l = a.stats + (int64_t)h * a.stats_stride + l31;
+    auto load_stats = [&](float2 (&st)[SC_TILE / 32], int t) {
+#pragma unroll
+        for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = stats_l[t * SC_TILE + kb * 32];
+    };
+    auto load_frags = [&](u32x4 (&fr)[C::KK], const char* buf, int kb) {
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk)
+            fr[kk] = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
     };
 
-    float best = -INFINITY;
-    if (t_begin < t_end) {
-        stage_tile<D, NWAVES>(lds, t_begin * SC_TILE, rowptr, wave, lane);
-        float2 sst = load_stat(t_begin);
-        if (threadIdx.x < SC_TILE) lstat[threadIdx.x] = sst;
-        __syncthreads();
+    float best[16], hold[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) best[i] = -INFINITY;
 
-        for (int t = t_begin; t < t_end; ++t) {
-            const int cur = (t - t_begin) & 1;
-            const char* buf = lds + cur * C::TILE_BYTES;
-            const float2* ls = lstat + cur * SC_TILE;
+    // one 128-row tile = 4 blocks of 32 query rows; log-softmax t = (x - m_r) - log l_r, running maximum per key.
+    // Two blocks share one v_max3_f32 per key.
+    auto tile_body = [&](const char* buf, const float2 (&st)[SC_TILE / 32]) {
+        u32x4 fr[C::KK];
+        load_frags(fr, buf, 0);
+#pragma unroll
+        for (int kb = 0; kb < SC_TILE / 32; ++kb) {
+            f16v acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[kk]), acc);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float neg_mr = -st[kb].x, ll = st[kb].y;
+            uint32_t xp[8];
+            float av[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) av[i] = acc[i];
+            chain_block<T, FAST, false>(av, xp, a.c, a.rcp);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float t0 = pair_sub<T, 0>(xp[p], neg_mr) - ll;
+                const float t1 = pair_sub<T, 1>(xp[p], neg_mr) - ll;
+                if (kb & 1) {
+                    best[2 * p] = fmaxf(fmaxf(best[2 * p], hold[2 * p]), t0);
+                    best[2 * p + 1] = fmaxf(fmaxf(best[2 * p + 1], hold[2 * p + 1]), t1);
+                } else {
+                    hold[2 * p] = t0;
+                    hold[2 * p + 1] = t1;
+                }
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        float2 st_a[SC_TILE / 32], st_b[SC_TILE / 32];
+        stage(lds, t_begin);
+        load_stats(st_a, t_begin);
+        stage_wait();
+            __syncthreads();
+        // two tiles per trip so that the statistics prefetched for tile t+1 need no register copies
+        for (int t = t_begin; t < t_end; t += 2) {
             if (t + 1 < t_end) {
-                stage_tile<D, NWAVES>(lds + (cur ^ 1) * C::TILE_BYTES, (t + 1) * SC_TILE, rowptr, wave, lane);
-                sst = load_stat(t + 1);
+                stage(lds + C::TILE_BYTES, t + 1);
+                load_stats(st_b, t + 1);
             }
-#pragma unroll 1
-            for (int kb = 0; kb < SC_TILE / 32; ++kb) {
-                f16v acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < C::KK; ++kk) {
-                    const u32x4 raw = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
-                    acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, raw), bk[kk], acc);
-                }
-                float b0 = -INFINITY, b1 = -INFINITY;
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const int rr = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    const float2 s0 = ls[rr], s1 = ls[rr + 1];
-                    b0 = fmaxf(b0, ((float)round_chain_h<T, FAST>(acc[i], a.c, a.rcp) - s0.x) - s0.y);
-                    b1 = fmaxf(b1, ((float)round_chain_h<T, FAST>(acc[i + 1], a.c, a.rcp) - s1.x) - s1.y);
-                }
-                best = fmaxf(best, fmaxf(b0, b1));
+            tile_body(lds, st_a);
+            stage_wait();
+            __syncthreads();  // next tile landed (vmcnt drained) and everybody is done reading this one
+            if (t + 1 >= t_end) break;
+            if (t + 2 < t_end) {
+                stage(lds, t + 2);
+                load_stats(st_a, t + 2);
             }
-            if (t + 1 < t_end && threadIdx.x < SC_TILE) lstat[(cur ^ 1) * SC_TILE + threadIdx.x] = sst;
+            tile_body(lds + C::TILE_BYTES, st_b);
+            stage_wait();
             __syncthreads();
         }
     }
-    best = fmaxf(best, __shfl_xor(best, 32, 64));
-    if (half == 0 && jvalid) a.colpart[((int64_t)ysplit * a.n_kv_heads + h) * a.m + j] = best;
+    // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float b = best[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+        best[i] = b;
+    }
+    if (l31 == 0) {
+        float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (j < a.m) dst[j] = best[i];
+        }
+    }
 }
 
 template <typename T>
@@ -522,21 +958,21 @@ static float find_exact_reciprocal(float c, int dtype) {
 template <typename T, int D, bool FAST>
 static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     const int R = a.G * a.q_len;
+    a.n_kv_heads = Hkv;
     {
+        const int items = (R + PA_ROWS - 1) / PA_ROWS * Hkv * a.key_splits;
+        const int blocks = min(items, SC_PERSISTENT_BLOCKS);
         ProfScope ps("score_rowstat", stream);
-        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3((R + PA_WAVES * 32 - 1) / (PA_WAVES * 32), Hkv, a.key_splits),
-                           dim3(PA_WAVES * 64), 0, stream, a);
+        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_rowstat_kernel");
     {
-        const int64_t rows_total = (int64_t)Hkv * R;
-        hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a.stats,
-                           a.key_splits, rows_total);
+        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
+        hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, R, rows_total);
     }
     KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
     const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
-    a.n_kv_heads = Hkv;
     {
         ProfScope ps("score_colmax", stream);
         hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
@@ -557,14 +993,18 @@ static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream) {
 using namespace kvz;
 
 
+static inline int score_stats_stride(int G, int q_len) { return (G * q_len + SC_TILE - 1) / SC_TILE * SC_TILE; }
 static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
-    return align256((size_t)score_key_splits(sink, m, q_len) * Hkv * G * q_len * sizeof(float2));
+    return align256((size_t)score_key_splits(sink, m, q_len) * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
+}
+
+static inline size_t score_colpart_bytes(int Hkv, int G, int q_len, int m) {
+    return align256((size_t)score_row_splits(Hkv, G, q_len, m) * Hkv * m * sizeof(float));
 }
 
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0 || sink < 0) return 0;
-    return score_stats_bytes(Hkv, G, q_len, m, sink) +
-           align256((size_t)score_row_splits(Hkv, G, q_len, m) * Hkv * m * sizeof(float));
+    return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m);
 }
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -588,6 +1028,7 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     a.klen = klen; a.sink = sink; a.start = start; a.m = m; a.q_len = q_len; a.G = G;
     a.stats = reinterpret_cast<float2*>(ws);
     a.key_splits = score_key_splits(sink, m, q_len);
+    a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}

@@ -310,6 +310,27 @@ def test_score_chunk_vs_oracle_multi_tile(dtype):
     assert exact >= 0.97 and within1 >= 0.995 and worst <= 8, (exact, within1, worst)
 
 
+@pytest.mark.parametrize("shape", [(14, 2, 64, 30, 2048, 30, 2030, 2013), (28, 4, 128, 32, 8192, 4032, 6032, 2026),
+                                   (32, 8, 128, 32, 3000, 732, 2732, 2026), (8, 2, 128, 16, 900, 16, 916, 37)])
+def test_score_chunk_is_deterministic(shape):
+    """Race detector for the hand-pipelined kernels (LDS-DMA, bare barriers, register prefetch): the same inputs must give
+    bit-identical scores run after run, with an unrelated launch of another shape in between.  (The accuracy tests
+    above tolerate a few differing scores, so a rare data race - one was found this way during development - would
+    pass them.)"""
+    H, Hkv, D, sink, N, start, end, q_len = shape
+    g = torch.Generator(device=DEV).manual_seed(5)
+    other_q = torch.randn(1, 8, 300, 128, generator=g, device=DEV).half()
+    other_k = torch.randn(1, 2, 16 + 700 + 300, 128, generator=g, device=DEV).half()
+    for it in range(4):
+        q = torch.randn(1, H, q_len, D, generator=g, device=DEV).half()
+        k = torch.randn(1, Hkv, sink + N + q_len, D, generator=g, device=DEV).half()
+        first = ops().score_chunk(q, k, sink, start, end).view(torch.int16).clone()
+        for _ in range(3):
+            ops().score_chunk(other_q, other_k, 16, 100, 600)
+            again = ops().score_chunk(q, k, sink, start, end).view(torch.int16)
+            assert torch.equal(first, again), f"iteration {it}: {int((first != again).sum())} scores changed between runs"
+
+
 def test_score_then_select_end_to_end_hamming():
     """End to end: masks from HIP scores vs masks from oracle scores — Hamming distance reported and bounded."""
     Hkv, G, D, sink, N, q_len = 2, 4, 128, 16, 512, 270

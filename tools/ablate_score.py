@@ -9,42 +9,43 @@ def rep(s, old, new):
     assert old in s, old
     return s.replace(old, new)
 
-EXP0 = "ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xp[p]), L2E, -ml2_run));"
-EXP1 = "ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xp[p]), L2E, -ml2_run));"
-variants = {
-    "base": lambda s: s,
-    "noexp": lambda s: rep(rep(s, EXP0, "ps0 += __builtin_fmaf(pair_lo<T>(xp[p]), L2E, -ml2_run);"), EXP1,
-                           "ps1 += __builtin_fmaf(pair_hi<T>(xp[p]), L2E, -ml2_run);"),
-    "noexpfma": lambda s: rep(rep(s, EXP0, "ps0 += __builtin_bit_cast(float, xp[p]);"), EXP1, ""),
-    "nomfma": lambda s: rep(s, "for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kk]), bq[kk], acc);",
-                            "for (int kk = 0; kk < C::KK; ++kk) { acc[2 * kk] += __builtin_bit_cast(float, fr[kk][0]); acc[2 * kk + 1] += __builtin_bit_cast(float, fr[kk][1]); }"),
-    "nostage": lambda s: rep(s, "if (t + 1 < t_hi) stage(next_buf, t + 1);", ""),
-    "nochainasm": lambda s: rep(s, 'asm(KVZ_MIX_ALL\n                "v_pk_max_f16 %[m0], %0, %1', 'asm("s_nop 0\\n\\t"\n                "v_pk_max_f16 %[m0], %0, %1'),
-}
-variants["fixedtile"] = lambda s: rep(s, "if (t + 1 < t_hi) stage(next_buf, t + 1);", "if (t + 1 < t_hi) stage(next_buf, t_lo);")
-variants["noepi_nomfma"] = lambda s: variants["nomfma"](variants["nochainasm"](variants["noexpfma"](s)))
-variants["noepi_fixedtile"] = lambda s: variants["fixedtile"](variants["nochainasm"](variants["noexpfma"](s)))
+def nofrag(s):
+    return rep(s, "            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);",
+               "            if (kb + 1 < SC_TILE / 32) { for (int kk = 0; kk < C::KK; ++kk) fr[(kb + 1) & 1][kk] = fr[kb & 1][kk] + 1u; }")
+def nostage(s):
+    return rep(s, "        if (linear) stage_tile_linear<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);\n        else stage_keys_gather",
+               "        if (t > 1) return;\n        if (linear) stage_tile_linear<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);\n        else stage_keys_gather")
+def noepi(s):
+    a = s.index("        uint32_t xp[8];\n        float av[16];\n        const int rel = rows.limit[g]")
+    b = s.index("        l_run[g] += ps0 + ps1;  // (masked keys")
+    return s[:a] + "        float ps0 = acc[0], ps1 = acc[7];\n" + s[b:]
+def nomfma(s):
+    s = rep(s, "                    acc0 = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[0][kk], acc0);\n                    acc1 = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[1][kk], acc1);",
+            "                    acc0[2 * kk] += __builtin_bit_cast(float, fr[kb & 1][kk][0]); acc0[2 * kk + 1] += __builtin_bit_cast(float, fr[kb & 1][kk][1]);\n                    acc1[2 * kk] += __builtin_bit_cast(float, fr[kb & 1][kk][2]); acc1[2 * kk + 1] += __builtin_bit_cast(float, fr[kb & 1][kk][3]);")
+    return s
+def nobarrier(s):
+    return rep(s, "        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more", "        // (no barrier)")
+variants = {"base": lambda s: s, "nofrag": nofrag, "nostage": nostage, "noepi": noepi, "nomfma": nomfma, "nobarrier": nobarrier,
+            "noepi_nomfma": lambda s: nomfma(noepi(s)), "nofrag_nostage": lambda s: nostage(nofrag(s))}
 def trace(s):
-    """In-kernel timeline of persistent pass A: s_memtime stamps (lane 0 of every wave of a few blocks).
-    Per tile 13 stamps: [after-mfma-issue, after-epilogue] x 3, then for the 4th block: after-mfma, after stage_wait,
-    after barrier, after stage issue, after frag prefetch issue, after epilogue."""
-    s = rep(s, "namespace kvz {\n\ntypedef _Float16 h8", "namespace kvz {\n__device__ unsigned long long g_trace[16 * 4 * 160];\n\ntypedef _Float16 h8")
-    s = rep(s, "    // ---- first item: static",
-            "    const bool trace = (blockIdx.x % 32 == 5 && lane == 0);\n"
-            "    unsigned long long* tr = g_trace + ((blockIdx.x / 32) * 4 + wave) * 160;\n"
+    """In-kernel timeline of pass A: s_memtime stamps kept in SGPR-fed registers and written to LDS-free global memory
+    (lane 0 of every wave of a few blocks).  Per tile 13 stamps: [after-mfma-issue, after-epilogues] x 3, then for the
+    4th block: after-mfma, after dma-wait, after barrier, after refill + frag prefetch issue, after epilogues."""
+    s = rep(s, "namespace kvz {\n\ntypedef _Float16 h8", "namespace kvz {\n__device__ unsigned long long g_trace[16 * 4 * 192];\n\ntypedef _Float16 h8")
+    s = rep(s, "    Item cur = item_from(0);\n",
+            "    const bool trace = (blockIdx.x % 16 == 5 && lane == 0);\n"
+            "    unsigned long long* tr = g_trace + ((blockIdx.x / 16) * 4 + wave) * 192;\n"
             "    int tp = 0;\n"
-            "#define STAMP() do { if (trace && tp < 158) tr[2 + tp++] = __builtin_amdgcn_s_memtime(); } while (0)\n"
+            "#define STAMP() do { if (trace && tp < 190) tr[2 + tp++] = __builtin_amdgcn_s_memtime(); } while (0)\n"
             "    if (trace) { tr[0] = 0; tr[1] = wall_clock64(); }\n"
             "    STAMP();\n"
-            "    // ---- first item: static")
-    s = rep(s, "                if (kb + 1 < SC_TILE / 32) load_frags(fr, cur_index, kb + 1);\n                else turnover(cur, cur_index ^ 1, t);\n",
-            "                STAMP();\n                if (kb + 1 < SC_TILE / 32) load_frags(fr, cur_index, kb + 1);\n                else turnover(cur, cur_index ^ 1, t);\n")
-    s = rep(s, "            stage_wait();     // my part of the tile in flight has landed\n            __syncthreads();  // ... everybody's has, and nobody reads `cur` any more\n",
-            "            stage_wait(); STAMP();\n            __syncthreads(); STAMP();\n")
-    s = rep(s, "                if (t + 2 < t_hi) stage(cur, kh, t + 2);\n                load_frags(fr, nxt_index, 0);\n",
-            "                if (t + 2 < t_hi) stage(cur, kh, t + 2);\n                STAMP();\n                load_frags(fr, nxt_index, 0);\n                STAMP();\n")
-    s = rep(s, "                    else epilogue(acc, k0, std::false_type{});\n                }\n            }\n        };",
-            "                    else epilogue(acc, k0, std::false_type{});\n                }\n                STAMP();\n            }\n        };")
+            "    Item cur = item_from(0);\n")
+    s = rep(s, "            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);\n            else turnover();\n",
+            "            STAMP();\n            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);\n            else { turnover(); STAMP(); }\n")
+    s = rep(s, "        stage_wait();     // my part of everything in flight (the next tile, the next item's query rows) has landed\n        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more\n",
+            "        stage_wait(); STAMP();\n        block_barrier(); STAMP();\n")
+    s = rep(s, "                else epilogue(acc1, k0, std::integral_constant<int, 1>{}, std::false_type{});\n            }\n        }\n    };",
+            "                else epilogue(acc1, k0, std::integral_constant<int, 1>{}, std::false_type{});\n            }\n            STAMP();\n        }\n    };")
     s += """
 extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace), bytes);
@@ -53,14 +54,13 @@ extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
     return s
 variants["trace"] = trace
 def gantt(s):
-    """Start / end wall-clock stamp (100 MHz), HW id and item count of every persistent pass A block."""
+    """Start / end wall-clock stamp (100 MHz), shader-clock ticks, item and tile count of every pass A block."""
     s = rep(s, "namespace kvz {\n\ntypedef _Float16 h8", "namespace kvz {\n__device__ unsigned long long g_trace[4 * 8192];\n\ntypedef _Float16 h8")
-    s = rep(s, "    // ---- first item ----\n", "    const int bid = blockIdx.x; int n_items = 0, n_tiles = 0;\n"
+    s = rep(s, "    Item cur = item_from(0);\n", "    const int bid = blockIdx.x; int n_items = 0, n_tiles = 0;\n"
             "    if (threadIdx.x == 0) { g_trace[4 * bid] = wall_clock64(); g_trace[4 * bid + 1] = 0; g_trace[4 * bid + 2] = __builtin_amdgcn_s_memtime(); }\n"
-            "    // ---- first item ----\n")
-    s = rep(s, "        if (next_id >= nitems) break;\n        it = nit;", "        ++n_items; n_tiles += t_hi - t_lo;\n        if (next_id >= nitems) break;\n        it = nit;")
-    s = rep(s, "        for (int kk = 0; kk < C::KK; ++kk) bq[kk] = bq_next[kk];\n    }\n}",
-            "        for (int kk = 0; kk < C::KK; ++kk) bq[kk] = bq_next[kk];\n    }\n"
+            "    Item cur = item_from(0);\n")
+    s = rep(s, "        if (!valid(nxt)) break;\n", "        ++n_items; n_tiles += cur.t_hi - cur.t_lo;\n        if (!valid(nxt)) break;\n")
+    s = rep(s, "        start_item();\n    }\n}", "        start_item();\n    }\n"
             "    if (threadIdx.x == 0) { g_trace[4 * bid + 1] = wall_clock64(); g_trace[4 * bid + 2] = __builtin_amdgcn_s_memtime() - g_trace[4 * bid + 2]; g_trace[4 * bid + 3] = ((unsigned long long)n_items << 32) | n_tiles; }\n}")
     s += """
 extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
@@ -69,29 +69,9 @@ extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
 """
     return s
 variants["gantt"] = gantt
-W = 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); '
-variants["w_turn"] = lambda s: rep(s, "                load_frags(fr, nxt_index, 0);", "                " + W + "load_frags(fr, nxt_index, 0);")
-variants["w_start"] = lambda s: rep(s, "        load_frags(fr, 0, 0);", "        " + W + "load_frags(fr, 0, 0);")
-variants["w_both"] = lambda s: variants["w_turn"](variants["w_start"](s))
-variants["w_kb"] = lambda s: rep(s, "                if (kb + 1 < SC_TILE / 32) load_frags(fr, cur_index, kb + 1);", "                if (kb + 1 < SC_TILE / 32) { " + W + "load_frags(fr, cur_index, kb + 1); }")
-def cfrags(s):
-    """compiler-visible fragment reads (the LDS-DMA alias wait comes back) - race bisection"""
-    a = s.index("template <int D>\n__device__ static inline void frag_load(")
-    b = s.index("template <int KK>\n__device__ static inline void frag_wait(")
-    new = """template <int D>
-__device__ static inline void frag_load(u32x4 (&fr)[D / 16], const FragAddr<D>& fa, int byte_off) {
-    typedef const __attribute__((address_space(3))) u32x4* lp;
-#pragma unroll
-    for (int kk = 0; kk < D / 16; ++kk) fr[kk] = *(lp)(uintptr_t)(fa.a[kk] + byte_off);
-}
-"""
-    return s[:a] + new + s[b:]
-variants["cfrags"] = cfrags
-variants["qturn"] = lambda s: rep(rep(s, "                stage(buf0, head_keys(nit.h), nit.t_lo);\n", "                stage(buf0, head_keys(nit.h), nit.t_lo);\n                nrow = row_of(nit);\n                load_q(bq_next, nrow.qp);\n"),
-                                  "        if (next_id < nitems) {\n            nrow = row_of(nit);\n            load_q(bq_next, nrow.qp);\n        }\n", "")
-variants["ks2"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 8", "#define KVZ_KSPLIT_TILES 2")
-variants["ks4"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 8", "#define KVZ_KSPLIT_TILES 4")
-variants["noepi"] = lambda s: variants["nochainasm"](variants["noexpfma"](s))
+variants["w4rg2"] = lambda s: rep(s, "#define KVZ_PA_WAVES 8\n#define KVZ_PA_RG 1", "#define KVZ_PA_WAVES 4\n#define KVZ_PA_RG 2")
+variants["ks2"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 2")
+variants["ks8"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 8")
 os.makedirs(os.path.join(ROOT, "tools/ab"), exist_ok=True)
 objs = [os.path.join(CS, o) for o in ("kvz_api.o", "kvz_select.o", "kvz_compact.o", "kvz_attn.o")]
 only = sys.argv[1:]

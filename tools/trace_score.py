@@ -24,11 +24,11 @@ _lib.load()
 for _ in range(3):
     ops.score_chunk(q, k, sink, start, start + m)
 torch.cuda.synchronize()
-buf = np.zeros(16 * 4 * 160, dtype=np.uint64)
+buf = np.zeros(16 * 4 * 192, dtype=np.uint64)
 raw = C.CDLL(os.environ["KVZIP_HIP_LIB"])
 raw.kvz_debug_read_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert raw.kvz_debug_read_trace(buf.ctypes.data, buf.nbytes) == 0
-tr = buf.reshape(16, 4, 160)
+tr = buf.reshape(16, 4, 192)
 for x in range(3):
     for w in range(4):
         s = tr[x, w]
@@ -36,8 +36,8 @@ for x in range(3):
         if len(st) < 14:
             continue
         d = np.diff(st)
-        print(f"block {x * 32 + 5} wave {w}: {len(st)} stamps, first gap (startup) {d[0]}")
+        print(f"block {x * 16 + 5} wave {w}: {len(st)} stamps, first gap (startup) {d[0]}")
         if w in (0, 2):
-            body = d[1:1 + ((len(d) - 1) // 12) * 12].reshape(-1, 12)
-            for ti, r in enumerate(body[:7]):  # the first item has 8 tiles; the last one has no stage/prefetch stamps
-                print(f"    tile {ti:2d}  mfma/epi: {r[0]}/{r[1]} {r[2]}/{r[3]} {r[4]}/{r[5]}  last: mfma {r[6]} dma-wait {r[7]} barrier {r[8]} stage {r[9]} frags {r[10]} epi {r[11]}   sum {r.sum()}")
+            body = d[1:1 + ((len(d) - 1) // 11) * 11].reshape(-1, 11)
+            for ti, r in enumerate(body[:12]):
+                print(f"    tile {ti:2d}  mfma/epi: {r[0]}/{r[1]} {r[2]}/{r[3]} {r[4]}/{r[5]}  last: mfma {r[6]} dma-wait {r[7]} barrier {r[8]} refill+frags {r[9]} epi {r[10]}   sum {r.sum()}")
