@@ -44,7 +44,12 @@ template <> struct Mfma32<__bf16> {
 };
 
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (2 x 32 KiB LDS buffers per block -> 2 blocks per CU)
-constexpr int PB_WAVES = 4;
+#ifndef KVZ_PB_WAVES
+#define KVZ_PB_WAVES 4
+#define KVZ_PB_OCC 2
+#endif
+constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
+constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
 #ifndef KVZ_KSPLIT_TILES
 #define KVZ_KSPLIT_TILES 4
 #endif
@@ -699,12 +704,16 @@ __global__ void score_merge_stats_kernel(ScoreArgs a, int R, int64_t rows_total)
 
 // ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
     constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES];
+    // two query-row tile buffers + the (m_r, log l_r) pairs of their 128 rows.  As in pass A nothing but LDS-DMA touches
+    // global memory inside the loop: a register-destination load there makes the compiler wait on the counter that also
+    // holds the tile in flight.
+    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
+    char* const lstat = lds + 2 * C::TILE_BYTES;
 
     // XCD-aware block order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The blocks that stream the SAME
     // query-row tiles (same row slice and head, different ctx-key tile) get ids that are congruent mod 8 whenever
@@ -728,6 +737,8 @@ __global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArg
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk)
             ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for these loads belongs here
     }
     // this block's slice of the query rows (tiles of 128); the host picks row_splits so that no slice is empty
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
@@ -744,7 +755,11 @@ __global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArg
     };
     const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
     // stage query-row tile t: linear when its 128 rows belong to one query head of the group
-    auto stage = [&](char* dst, int t) {
+    // merged statistics (m_r, log l_r); the array is padded to whole tiles with (+inf, 0): one 1-KiB DMA per tile
+    const char* stats_h = reinterpret_cast<const char*>(a.stats + (int64_t)h * a.stats_stride);
+    auto stage = [&](int b, int t) {
+        char* dst = lds + b * C::TILE_BYTES;
+        if (wave == 0) lds_dma16(stats_h + (int64_t)t * SC_TILE * 8 + lane * 16, lstat + b * SC_TILE * 8);
         const int r0 = t * SC_TILE, r1 = r0 + SC_TILE - 1;
         const int g0 = r0 / a.q_len;
         const int qi0 = r0 - g0 * a.q_len;
@@ -752,13 +767,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArg
             stage_tile_linear<D, NWAVES>(dst, qbase + ((int64_t)g0 * a.q_head_stride + (int64_t)qi0 * D) * 2, lane_off, wave);
         else
             stage_tile<D, NWAVES>(dst, r0, rowptr, wave, lane);
-    };
-    // merged statistics (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of a tile; the array is
-    // padded to whole tiles with (+inf, 0), so the loads are unconditional
-    const float2* stats_l = a.stats + (int64_t)h * a.stats_stride + l31;
-    auto load_stats = [&](float2 (&st)[SC_TILE / 32], int t) {
-#pragma unroll
-        for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = stats_l[t * SC_TILE + kb * 32];
     };
     auto load_frags = [&](u32x4 (&fr)[C::KK], const char* buf, int kb) {
 #pragma unroll
@@ -772,9 +780,13 @@ __global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArg
 
     // one 128-row tile = 4 blocks of 32 query rows; log-softmax t = (x - m_r) - log l_r, running maximum per key.
     // Two blocks share one v_max3_f32 per key.
-    auto tile_body = [&](const char* buf, const float2 (&st)[SC_TILE / 32]) {
+    auto tile_body = [&](int b) {
+        const char* buf = lds + b * C::TILE_BYTES;
         u32x4 fr[C::KK];
         load_frags(fr, buf, 0);
+        float2 st[SC_TILE / 32];  // this lane's query row in each of the four 32-row blocks of the tile
+#pragma unroll
+        for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = *reinterpret_cast<const float2*>(lstat + (b * SC_TILE + kb * 32 + l31) * 8);
 #pragma unroll
         for (int kb = 0; kb < SC_TILE / 32; ++kb) {
             f16v acc;
@@ -807,28 +819,20 @@ __global__ __launch_bounds__(PB_WAVES * 64, 2) void score_colmax_kernel(ScoreArg
     };
 
     if (t_begin < t_end) {
-        float2 st_a[SC_TILE / 32], st_b[SC_TILE / 32];
-        stage(lds, t_begin);
-        load_stats(st_a, t_begin);
+        stage(0, t_begin);
         stage_wait();
-            __syncthreads();
-        // two tiles per trip so that the statistics prefetched for tile t+1 need no register copies
+        block_barrier();
+        // two tiles per trip: both buffers have compile-time addresses
         for (int t = t_begin; t < t_end; t += 2) {
-            if (t + 1 < t_end) {
-                stage(lds + C::TILE_BYTES, t + 1);
-                load_stats(st_b, t + 1);
-            }
-            tile_body(lds, st_a);
+            if (t + 1 < t_end) stage(1, t + 1);
+            tile_body(0);
             stage_wait();
-            __syncthreads();  // next tile landed (vmcnt drained) and everybody is done reading this one
+            block_barrier();  // next tile landed and everybody is done reading this one
             if (t + 1 >= t_end) break;
-            if (t + 2 < t_end) {
-                stage(lds, t + 2);
-                load_stats(st_a, t + 2);
-            }
-            tile_body(lds + C::TILE_BYTES, st_b);
+            if (t + 2 < t_end) stage(0, t + 2);
+            tile_body(1);
             stage_wait();
-            __syncthreads();
+            block_barrier();
         }
     }
     // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half

@@ -28,24 +28,21 @@ def nobarrier(s):
 variants = {"base": lambda s: s, "nofrag": nofrag, "nostage": nostage, "noepi": noepi, "nomfma": nomfma, "nobarrier": nobarrier,
             "noepi_nomfma": lambda s: nomfma(noepi(s)), "nofrag_nostage": lambda s: nostage(nofrag(s))}
 def trace(s):
-    """In-kernel timeline of pass A: s_memtime stamps kept in SGPR-fed registers and written to LDS-free global memory
-    (lane 0 of every wave of a few blocks).  Per tile 13 stamps: [after-mfma-issue, after-epilogues] x 3, then for the
-    4th block: after-mfma, after dma-wait, after barrier, after refill + frag prefetch issue, after epilogues."""
-    s = rep(s, "namespace kvz {\n\ntypedef _Float16 h8", "namespace kvz {\n__device__ unsigned long long g_trace[16 * 4 * 192];\n\ntypedef _Float16 h8")
+    """Light in-kernel timeline of pass A: three s_memtime stamps per tile (tile start, arrival at the hand-over barrier,
+    release from it), consumed only at the end of the tile so that the fragment prefetch is not disturbed."""
+    s = rep(s, "namespace kvz {\n\ntypedef _Float16 h8", "namespace kvz {\n__device__ unsigned long long g_trace[16 * 8 * 96];\n\ntypedef _Float16 h8")
     s = rep(s, "    Item cur = item_from(0);\n",
             "    const bool trace = (blockIdx.x % 16 == 5 && lane == 0);\n"
-            "    unsigned long long* tr = g_trace + ((blockIdx.x / 16) * 4 + wave) * 192;\n"
+            "    unsigned long long* tr = g_trace + ((blockIdx.x / 16) * 8 + wave) * 96;\n"
             "    int tp = 0;\n"
-            "#define STAMP() do { if (trace && tp < 190) tr[2 + tp++] = __builtin_amdgcn_s_memtime(); } while (0)\n"
-            "    if (trace) { tr[0] = 0; tr[1] = wall_clock64(); }\n"
-            "    STAMP();\n"
+            "    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;\n"
             "    Item cur = item_from(0);\n")
-    s = rep(s, "            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);\n            else turnover();\n",
-            "            STAMP();\n            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);\n            else { turnover(); STAMP(); }\n")
     s = rep(s, "        stage_wait();     // my part of everything in flight (the next tile, the next item's query rows) has landed\n        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more\n",
-            "        stage_wait(); STAMP();\n        block_barrier(); STAMP();\n")
-    s = rep(s, "                else epilogue(acc1, k0, std::integral_constant<int, 1>{}, std::false_type{});\n            }\n        }\n    };",
-            "                else epilogue(acc1, k0, std::integral_constant<int, 1>{}, std::false_type{});\n            }\n            STAMP();\n        }\n    };")
+            "        stage_wait();\n        ts1 = __builtin_amdgcn_s_memtime();\n        block_barrier();\n        ts2 = __builtin_amdgcn_s_memtime();\n")
+    s = rep(s, "    while (true) {\n        if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(std::true_type{});",
+            "    while (true) {\n        ts0 = __builtin_amdgcn_s_memtime();\n        if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(std::true_type{});")
+    s = rep(s, "        pbuf ^= 1;\n        ahead = ahead_next;\n",
+            "        if (trace && tp < 30) { tr[3 * tp] = ts0; tr[3 * tp + 1] = ts1; tr[3 * tp + 2] = ts2; ++tp; }\n        pbuf ^= 1;\n        ahead = ahead_next;\n")
     s += """
 extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace), bytes);
@@ -69,6 +66,32 @@ extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
 """
     return s
 variants["gantt"] = gantt
+variants["pb8x4"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 8\n#define KVZ_PB_OCC 4")
+variants["pb4x3"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 3")
+variants["pb8x2"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 8\n#define KVZ_PB_OCC 2")
+def split2(s):
+    """two independent accumulators per row group (even / odd k-steps), summed before the epilogue"""
+    return rep(s, """#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk)
+#pragma unroll
+                for (int g = 0; g < PA_RG; ++g)
+                    if (!skip[g]) acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);""",
+               """            f16v acc2[PA_RG];
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[g][i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; kk += 2)
+#pragma unroll
+                for (int g = 0; g < PA_RG; ++g)
+                    if (!skip[g]) {
+                        acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);
+                        acc2[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk + 1]), bq[g][kk + 1], acc2[g]);
+                    }
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g) acc[g] += acc2[g];""")
+variants["split2"] = split2
 variants["w4rg2"] = lambda s: rep(s, "#define KVZ_PA_WAVES 8\n#define KVZ_PA_RG 1", "#define KVZ_PA_WAVES 4\n#define KVZ_PA_RG 2")
 variants["ks2"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 2")
 variants["ks8"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 8")

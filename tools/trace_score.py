@@ -24,20 +24,20 @@ _lib.load()
 for _ in range(3):
     ops.score_chunk(q, k, sink, start, start + m)
 torch.cuda.synchronize()
-buf = np.zeros(16 * 4 * 192, dtype=np.uint64)
+buf = np.zeros(16 * 8 * 96, dtype=np.uint64)
 raw = C.CDLL(os.environ["KVZIP_HIP_LIB"])
 raw.kvz_debug_read_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert raw.kvz_debug_read_trace(buf.ctypes.data, buf.nbytes) == 0
-tr = buf.reshape(16, 4, 192)
-for x in range(3):
-    for w in range(4):
-        s = tr[x, w]
-        st = [int(v) for v in s[2:] if v]
-        if len(st) < 14:
-            continue
-        d = np.diff(st)
-        print(f"block {x * 16 + 5} wave {w}: {len(st)} stamps, first gap (startup) {d[0]}")
-        if w in (0, 2):
-            body = d[1:1 + ((len(d) - 1) // 11) * 11].reshape(-1, 11)
-            for ti, r in enumerate(body[:12]):
-                print(f"    tile {ti:2d}  mfma/epi: {r[0]}/{r[1]} {r[2]}/{r[3]} {r[4]}/{r[5]}  last: mfma {r[6]} dma-wait {r[7]} barrier {r[8]} refill+frags {r[9]} epi {r[10]}   sum {r.sum()}")
+tr = buf.reshape(16, 8, 32, 3).astype(np.int64)
+for x in range(2):
+    n = int((tr[x, 0, :, 0] > 0).sum())
+    if n < 3:
+        continue
+    t0 = tr[x, :, 0, 0].min()
+    print(f"block {x * 16 + 5}: {n} tiles traced; per tile: start (relative to block start), then per wave [compute-until-barrier / wait-at-barrier]")
+    for ti in range(min(n, 14)):
+        start = tr[x, :, ti, 0] - t0
+        comp = tr[x, :, ti, 1] - tr[x, :, ti, 0]
+        wait = tr[x, :, ti, 2] - tr[x, :, ti, 1]
+        nxt = (tr[x, :, ti + 1, 0] - tr[x, :, ti, 2]) if ti + 1 < n else np.zeros(8, dtype=np.int64)
+        print(f"  tile {ti:2d} start {int(start.min()):7d}  " + " ".join(f"{int(c)}/{int(w)}" for c, w in zip(comp, wait)) + f"   after-barrier part (epilogue etc.): {int(nxt.mean())}")
