@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--q-pool", type=int, default=0, help="distinct chunk inputs kept in HBM (0 = all chunks)")
+    ap.add_argument("--prof-period", type=int, default=8,
+                    help="bracket every n-th launch of each kernel with hipEvents inside the timed region (1 = every launch; "
+                         "an event pair costs ~2.5 us of stream time, ~6 %% of a scoring call when every kernel is bracketed)")
     return ap.parse_args()
 
 
@@ -172,7 +175,7 @@ def main():
     for _ in range(args.warmup):
         kv, thres, r_real = one_step()
     lib.kvz_prof_reset()
-    lib.kvz_prof_enable(1)
+    lib.kvz_prof_enable(max(1, args.prof_period))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -271,7 +274,8 @@ def main():
             "bound": "mfma", "kernel": dominant, "achieved": dom_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": None,
             "note": ("algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) launch (QK^T only, SURVEY §8d); "
-                     "score_combined = same flops over rowstat+colmax time"),
+                     "score_combined = same flops over rowstat+colmax time; kernel durations from hipEvents on the launch "
+                     f"stream inside the timed region, every {max(1, args.prof_period)}th launch of each kernel bracketed"),
         },
         "roofline_stages": {
             "score_rowstat": {"bound": "mfma", "achieved": a_tf, "unit": "TFLOP/s", "frac": a_tf / MFMA_PEAK_TFLOPS,

@@ -44,9 +44,11 @@ const char* kvz_last_error(void);
 
 /* Optional measurement hook (no reference counterpart; the reference times with torch.cuda.synchronize() +
  * wall clock, utils/func.py:52-79): when enabled, the dominant kernels are bracketed by hipEvents recorded on
- * the launch stream.  kvz_prof_read synchronises on the recorded events and returns the accumulated time and
- * launch count of kernel `name` ("score_rowstat", "score_colmax", "compact_gather", "select", "varlen_attn"). */
-void kvz_prof_enable(int on);
+ * the launch stream.  `period` = 0 switches it off, 1 brackets every launch, n brackets every n-th launch of each
+ * kernel (an event pair costs ~2.5 us of stream time per bracketed launch).  kvz_prof_read synchronises on the recorded
+ * events and returns the accumulated time and the number of BRACKETED launches of kernel `name` ("score_rowstat",
+ * "score_colmax", "compact_gather", "select", "varlen_attn"). */
+void kvz_prof_enable(int period);
 void kvz_prof_reset(void);
 int kvz_prof_read(const char* name, double* total_ms, int64_t* count);
 

@@ -21,8 +21,9 @@ struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double total_ms = 0.0;
     int64_t count = 0;
+    int64_t seen = 0;  // launches since the last reset (sampled or not)
 };
-static bool g_prof_on = false;
+static int g_prof_period = 0;  // 0 = off, n = bracket every n-th launch of each kernel
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_free_events;
@@ -38,7 +39,7 @@ static hipEvent_t get_event() {
     return e;
 }
 
-bool prof_enabled() { return g_prof_on; }
+bool prof_enabled() { return g_prof_period > 0; }
 
 void prof_begin(const char* name, hipStream_t stream, int* slot, size_t* idx) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -49,6 +50,10 @@ void prof_begin(const char* name, hipStream_t stream, int* slot, size_t* idx) {
         g_prof.push_back(ProfEntry{});
         g_prof.back().name = name;
         s = (int)g_prof.size() - 1;
+    }
+    if (g_prof[s].seen++ % g_prof_period != 0) {  // not a sampled launch
+        *slot = -1;
+        return;
     }
     hipEvent_t a = get_event(), b = get_event();
     (void)hipEventRecord(a, stream);
@@ -84,12 +89,12 @@ extern "C" const char* kvz_last_error(void) { return kvz::g_err; }
 
 extern "C" void kvz_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(kvz::g_prof_mu);
-    kvz::g_prof_on = on != 0;
+    kvz::g_prof_period = on > 0 ? on : 0;
 }
 extern "C" void kvz_prof_reset(void) {
     std::lock_guard<std::mutex> lk(kvz::g_prof_mu);
     kvz::prof_collect();
-    for (auto& e : kvz::g_prof) { e.total_ms = 0.0; e.count = 0; }
+    for (auto& e : kvz::g_prof) { e.total_ms = 0.0; e.count = 0; e.seen = 0; }
 }
 extern "C" int kvz_prof_read(const char* name, double* total_ms, int64_t* count) {
     std::lock_guard<std::mutex> lk(kvz::g_prof_mu);
