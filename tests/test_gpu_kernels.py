@@ -310,6 +310,29 @@ def test_score_chunk_vs_oracle_multi_tile(dtype):
     assert exact >= 0.97 and within1 >= 0.995 and worst <= 8, (exact, within1, worst)
 
 
+@pytest.mark.parametrize("H,Hkv,D,sink,N,start,m,q_len", [
+    (4, 2, 128, 16, 400, 16 + 37, 304, 200),     # 520 keys = 5 key tiles: every row tile ends with a key slice of ONE tile
+    (4, 2, 128, 0, 300, 10, 60, 60),             # 120 keys: a single key tile, items of one tile only (starved stream)
+    (2, 1, 128, 8, 900, 8 + 100, 520, 129),      # Hkv = 1, 9 tiles; 258 rows -> a second row tile with 2 valid rows
+    (6, 6, 64, 4, 700, 4 + 3, 5, 300),           # G = 1, five ctx keys only, D = 64
+    (8, 2, 128, 32, 640, 32 + 128, 3, 7),        # three ctx keys, seven query rows
+    (16, 2, 64, 30, 1200, 30 + 400, 513, 77),    # G = 8, 620 keys (5 tiles), rows spanning several query heads per tile
+    (28, 4, 128, 32, 2100, 32, 2000, 2013),      # first chunk of the headline geometry (q = m + 13)
+])
+def test_score_chunk_edge_shapes(H, Hkv, D, sink, N, start, m, q_len):
+    """Shapes that exercise the corners of the persistent pipeline: key slices of a single tile (late staging path), work lists
+    shorter than the grid, partial row tiles, G = 1 / Hkv = 1, a handful of ctx keys or query rows."""
+    g = torch.Generator().manual_seed(H * 1000 + m)
+    q = torch.randn(1, H, q_len, D, generator=g).half()
+    k = torch.randn(1, Hkv, sink + N + q_len, D, generator=g).half()
+    want = orc.get_score(q, k, sink, start, start + m)
+    got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, start, start + m).cpu()
+    exact, within1, worst = _score_stats(got, want)
+    assert exact >= 0.97 and within1 >= 0.995 and worst <= 8, (exact, within1, worst)
+    again = ops().score_chunk(q.to(DEV), k.to(DEV), sink, start, start + m).cpu()
+    assert torch.equal(got.view(torch.int16), again.view(torch.int16))
+
+
 @pytest.mark.parametrize("shape", [(14, 2, 64, 30, 2048, 30, 2030, 2013), (28, 4, 128, 32, 8192, 4032, 6032, 2026),
                                    (32, 8, 128, 32, 3000, 732, 2732, 2026), (8, 2, 128, 16, 900, 16, 916, 37)])
 def test_score_chunk_is_deterministic(shape):
