@@ -474,11 +474,14 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
         return w;
     };
     // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use
-    auto load_frags = [&](u32x4 (&fr)[C::KK], int b /* runtime buffer */, int kb /* compile-time */) __attribute__((always_inline)) {
-        FragAddr<D> fb;
+    // (the addresses of the buffer in use are computed once per tile: fcur)
+    FragAddr<D> fcur = fa0;
+    auto set_frag_buffer = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) fb.a[kk] = fa0.a[kk] + (uint32_t)(b * C::TILE_BYTES);
-        frag_load<D>(fr, fb, kb * 32 * C::ROW_BYTES);
+        for (int kk = 0; kk < C::KK; ++kk) fcur.a[kk] = fa0.a[kk] + (uint32_t)(b * C::TILE_BYTES);
+    };
+    auto load_frags = [&](u32x4 (&fr)[C::KK], int kb /* compile-time */) __attribute__((always_inline)) {
+        frag_load<D>(fr, fcur, kb * 32 * C::ROW_BYTES);
     };
 
     Item cur = item_from(0);
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
     v8 bq[PA_RG][C::KK];
     read_q(bq);
     u32x4 fr[2][C::KK];
-    load_frags(fr[0], 0, 0);
+    load_frags(fr[0], 0);
 #pragma unroll
     for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
@@ -579,7 +582,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
         if (ahead) {  // normal case: tile p+1 is in the other buffer; refill this one with tile p+2
             ahead_next = !sq_done;
             if (!sq_done) sq_stage(pbuf);
-            load_frags(fr[0], pbuf ^ 1, 0);
+            set_frag_buffer(pbuf ^ 1);
+            load_frags(fr[0], 0);
         } else {      // the stream was starved (items of a single tile) or ends here: both buffers are free
             late = !sq_done;
             if (!sq_done) sq_stage(pbuf ^ 1);
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
 #pragma unroll
                 for (int g = 0; g < PA_RG; ++g)
                     if (!skip[g]) acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);
-            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
             else turnover();
             __builtin_amdgcn_sched_barrier(0);
             auto epi = [&](auto g_tag) __attribute__((always_inline)) {
@@ -630,7 +634,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
         if (late) {  // (rare) the next tile could only be staged at the hand-over: wait for it here
             stage_wait();
             block_barrier();
-            load_frags(fr[0], pbuf, 0);
+            set_frag_buffer(pbuf);
+            load_frags(fr[0], 0);
             late = false;
         }
         if (++t < cur.t_hi) continue;

@@ -65,6 +65,8 @@ class _CacheBase(KVScore):
 
     # -- dense (pre-prune) storage --------------------------------------------------------------
     def _dense_append(self, layer_idx: int, key_states: torch.Tensor, value_states: torch.Tensor):
+        # the previous (asynchronous) scoring call of this layer read the rows that are about to be overwritten
+        self._wait_score(layer_idx)
         t = key_states.shape[-2]
         if len(self._store_k) <= layer_idx:
             _, Hkv, _, D = key_states.shape

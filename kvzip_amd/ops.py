@@ -39,11 +39,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # a1  scoring
 # --------------------------------------------------------------------------------------------------
 def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int, start: int, end: int,
-                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
     """KV importance score of one layer / one chunk (reference attention/score.py:36-65).
 
     query_states ``[1, H, q, D]``, key_states ``[1, Hkv, klen, D]`` (rows contiguous; the head stride may be
     larger than ``klen*D`` — views into a cache with slack are fine).  Returns ``[1, Hkv, end-start]``.
+    ``stream``: launch there instead of on the current stream (``out`` and ``workspace`` must then be given: nothing is
+    allocated on a foreign stream).
     """
     lib = _lib.load()
     bsz, H, q_len, D = query_states.shape
@@ -57,6 +60,7 @@ def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int,
     assert key_states.dtype == query_states.dtype
     assert query_states.stride(-1) == 1 and query_states.stride(-2) == D
     assert key_states.stride(-1) == 1 and key_states.stride(-2) == D
+    assert stream is None or (out is not None and workspace is not None)
     if out is None:
         out = torch.empty((1, Hkv, m), dtype=query_states.dtype, device=query_states.device)
     assert out.stride(-1) == 1 and out.shape[-1] == m
@@ -66,7 +70,7 @@ def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int,
     rc = lib.kvz_score_chunk(query_states.data_ptr(), query_states.stride(1), key_states.data_ptr(),
                              key_states.stride(1), klen, sink, start, end, q_len, Hkv, G, D, dt,
                              out.data_ptr(), out.stride(1), workspace.data_ptr(), workspace.numel(),
-                             _stream(query_states))
+                             _stream(query_states) if stream is None else stream.cuda_stream)
     check(rc, "kvz_score_chunk")
     return out
 

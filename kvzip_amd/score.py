@@ -6,7 +6,14 @@ Differences that are deliberate (and invisible through the interface):
   * ``score[layer]`` are views into ONE preallocated ``[L, 1, Hkv, N]`` buffer that ``_get_score`` fills in
     place (the reference grows L tensors with ``torch.cat`` per chunk, score.py:33-34);
   * ``_threshold`` finds the order statistic with a radix histogram instead of a full sort (score.py:93);
-  * ``_threshold_uniform`` breaks ties towards the lowest index (``torch.topk`` leaves it unspecified).
+  * ``_threshold_uniform`` breaks ties towards the lowest index (``torch.topk`` leaves it unspecified);
+  * ``_get_score`` is ASYNCHRONOUS with respect to the caller's stream: the scores of a layer are a side product that
+    nothing in the forward pass consumes, so the kernels of consecutive layers are issued round-robin on
+    ``n_score_streams`` (default 2) side streams.  The tail of one persistent kernel, the launch gaps and the two tiny
+    merge / finalize kernels of a call then overlap with the big kernels of the next one (+16 % scoring throughput on
+    MI355X).  Ordering is kept with events: the side stream waits for the caller's stream (inputs), ``update`` of a layer
+    waits for that layer's previous scoring call (it overwrites the rows that call read), and reading ``.score``,
+    thresholding or pruning waits for everything outstanding.
 """
 from __future__ import annotations
 
@@ -15,6 +22,20 @@ from typing import List, Optional, Tuple, Union
 import torch
 
 from . import ops
+
+
+# Side streams are shared by all cache objects of a process: HIP spreads streams over a handful of hardware queues
+# (4 by default) in creation order, and two streams that land on the same queue do not overlap at all - which is what
+# happened when every cache object created its own pair.
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n: int):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 class KVScore:
@@ -27,13 +48,43 @@ class KVScore:
         self.device = None
         self.get_score = True
         self.causal_mask_score = None  # kept for interface compatibility; the mask is applied inside the kernel
-        self.score = None
+        self._score = None
         self.sink = None
         self.start_idx, self.end_idx = None, None
         self.ctx_len = None
         self._score_buf: Optional[torch.Tensor] = None
         self._score_fill: List[int] = []
-        self._score_ws: Optional[torch.Tensor] = None
+        self._score_ws: List[Optional[torch.Tensor]] = []
+        self.n_score_streams = 2       # 1 = score on the caller's stream
+        self._score_exclusive = False  # True: the next calls run alone on the caller's stream (clean kernel timings)
+        self._score_side: List["torch.cuda.Stream"] = []
+        self._score_events = {}        # layer -> event recorded after its latest scoring call
+        self._score_ev_pool = {}       # layer -> reusable event object
+
+    # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
+    @property
+    def score(self):
+        """Per-layer scores (reference attribute).  Reading it orders the caller's stream behind outstanding scoring."""
+        self._wait_score()
+        return self._score
+
+    @score.setter
+    def score(self, value):
+        self._score = value
+
+    def _wait_score(self, layer_idx: Optional[int] = None):
+        """Make the current stream wait for the scoring calls still in flight (of one layer, or of all)."""
+        if not self._score_events:
+            return
+        cur = torch.cuda.current_stream()
+        if layer_idx is None:
+            for ev in self._score_events.values():
+                cur.wait_event(ev)
+            self._score_events = {}
+        else:
+            ev = self._score_events.pop(layer_idx, None)
+            if ev is not None:
+                cur.wait_event(ev)
 
     # reference: attention/score.py:25-31
     def init_score(self):
@@ -41,8 +92,9 @@ class KVScore:
         self.causal_mask_score = None
         n = int(self.ctx_len) if self.ctx_len is not None else 0
         self._score_buf = torch.empty((self.n_layers, 1, self.n_heads_kv, n), dtype=self.dtype, device=self.device)
+        self._wait_score()
         self._score_fill = [0 for _ in range(self.n_layers)]
-        self.score = [self._score_buf[l][:, :, :0] for l in range(self.n_layers)]
+        self._score = [self._score_buf[l][:, :, :0] for l in range(self.n_layers)]
 
     # reference: attention/score.py:33-34
     def _update_score(self, layer_idx: int, score: torch.Tensor):
@@ -50,19 +102,21 @@ class KVScore:
         m = score.shape[-1]
         f = self._score_fill[layer_idx]
         self._ensure_score_capacity(f + m)
+        self._wait_score(layer_idx)
         self._score_buf[layer_idx][:, :, f:f + m].copy_(score)
         self._score_fill[layer_idx] = f + m
-        self.score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
+        self._score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
 
     def _ensure_score_capacity(self, need: int):
         if self._score_buf.shape[-1] >= need:
             return
+        self._wait_score()
         new = torch.empty((self.n_layers, 1, self.n_heads_kv, need), dtype=self.dtype, device=self.device)
         old = self._score_buf.shape[-1]
         if old:
             new[..., :old].copy_(self._score_buf)
         self._score_buf = new
-        self.score = [new[l][:, :, :self._score_fill[l]] for l in range(self.n_layers)]
+        self._score = [new[l][:, :, :self._score_fill[l]] for l in range(self.n_layers)]
 
     # reference: attention/score.py:36-65
     def _get_score(self, query_states: torch.Tensor, key_states: torch.Tensor, layer_idx: int):
@@ -74,12 +128,32 @@ class KVScore:
         out = self._score_buf[layer_idx][:, :, f:f + m]
         bsz, H, q_len, D = query_states.shape
         need = ops._lib.load().kvz_score_workspace_bytes(self.n_heads_kv, H // self.n_heads_kv, q_len, m, self.sink)
-        if self._score_ws is None or self._score_ws.numel() < need:
-            self._score_ws = torch.empty(need, dtype=torch.uint8, device=query_states.device)
-        ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,
-                        workspace=self._score_ws)
+        nstreams = 1 if (self._score_exclusive or not query_states.is_cuda) else max(1, int(self.n_score_streams))
+        slot = layer_idx % nstreams if nstreams > 1 else 0
+        while len(self._score_ws) <= slot:
+            self._score_ws.append(None)
+        if self._score_ws[slot] is None or self._score_ws[slot].numel() < need:
+            self._wait_score()  # (the old workspace of this slot may still be in use)
+            self._score_ws[slot] = torch.empty(need, dtype=torch.uint8, device=query_states.device)
+        if nstreams == 1:
+            self._wait_score()  # the caller's stream: everything before it is ordered anyway, later calls wait for it
+            ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,
+                            workspace=self._score_ws[0])
+        else:
+            self._score_side = _side_streams(query_states.device, nstreams)
+            side, cur = self._score_side[slot], torch.cuda.current_stream(query_states.device)
+            side.wait_stream(cur)                # the inputs (and this layer's cache update) were produced there
+            query_states.record_stream(side)     # a temporary of the forward pass must outlive the side stream's use
+            # (key_states is a view of the cache storage, which is only reallocated after _wait_score)
+            ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,
+                            workspace=self._score_ws[slot], stream=side)
+            ev = self._score_ev_pool.get(layer_idx)
+            if ev is None:
+                ev = self._score_ev_pool[layer_idx] = torch.cuda.Event()
+            ev.record(side)
+            self._score_events[layer_idx] = ev
         self._score_fill[layer_idx] = f + m
-        self.score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
+        self._score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
 
     # ------------------------------------------------------------------------------------------
     def _stacked_score(self, score) -> torch.Tensor:
