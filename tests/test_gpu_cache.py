@@ -189,3 +189,42 @@ def test_slack_growth_and_update_after_many_tokens():
     for h in range(Hkv):
         tail = kv.key_cache[0][seg[h] + lens[h]: seg[h] + lens[h] + 9]
         assert torch.equal(tail, torch.cat([n[0, h] for n in news]))
+
+
+def test_async_scoring_equals_single_stream():
+    """Scoring calls of consecutive layers overlap on side streams (kvzip_amd/score.py).  The result must be bit-identical to
+    the single-stream run through the whole update -> _get_score -> slice cycle: the next chunk's ``update`` overwrites the rows
+    the previous chunk's scoring of that layer read, so a missing event shows up as corrupted scores."""
+    from kvzip_amd.kvcache import EvictCache
+    L, H, Hkv, D, sink, N, chunk = 6, 8, 2, 128, 16, 1536, 256
+    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    K = [torch.randn(1, Hkv, sink + N, D, generator=g, device=DEV).half() for _ in range(L)]
+    V = [torch.randn(1, Hkv, sink + N, D, generator=g, device=DEV).half() for _ in range(L)]
+    chunks = [(sink + c, min(sink + c + chunk, sink + N)) for c in range(0, N, chunk)]
+    q_in = [[torch.randn(1, H, (en - st) + 9, D, generator=g, device=DEV).half() for _ in range(L)] for st, en in chunks]
+    k_in = [[torch.randn(1, Hkv, (en - st) + 9, D, generator=g, device=DEV).half() for _ in range(L)] for st, en in chunks]
+
+    def run(nstreams):
+        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=torch.float16, verbose=False)
+        kv.n_score_streams = nstreams
+        for l in range(L):
+            kv.update(K[l], V[l], l)
+        kv.init_score()
+        for c, (st, en) in enumerate(chunks):
+            kv.start_idx, kv.end_idx = st, en
+            seen = kv._seen_tokens
+            for l in range(L):
+                k_all, _ = kv.update(k_in[c][l], k_in[c][l], l)
+                kv._get_score(q_in[c][l], k_all, l)
+            kv.slice(seen)
+        kv.start_idx, kv.get_score = sink, False
+        score = torch.stack([s.clone() for s in kv.score])   # reading .score waits for the side streams
+        thres, r_real = kv.prune(0.4)
+        return score, thres, kv.valid.clone()
+
+    s1, t1, v1 = run(1)
+    for _ in range(3):
+        s2, t2, v2 = run(2)
+        assert torch.equal(s1.view(torch.int16), s2.view(torch.int16))
+        assert t1 == t2 and torch.equal(v1, v2)
