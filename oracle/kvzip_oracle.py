@@ -7,8 +7,9 @@ A plain restatement, on CPU tensors, of the reference algorithm for the KV-evict
 Parity status: PINNED for a1-a12/a14 — every function below is checked bit-for-bit against golden vectors
 produced by importing the reference's own Python (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``).
 ``varlen_attn`` (a13) restates flash-attn 2.7.4.post1's published semantics (third party, absent from
-/root/reference): PARITY UNPINNED at that boundary; it is anchored on the reference's call site and on
-the identity "compacted varlen attention == dense attention with evicted keys masked".
+/root/reference): PARITY UNPINNED at that boundary; it is anchored on the reference's call site, on the identity
+"compacted varlen attention == dense attention with evicted keys masked" and on an independent implementation of the
+published semantics (torch's math-backend SDPA with a bottom-right aligned causal mask, tests/test_oracle_golden.py).
 
 Each function cites the reference lines it follows (paths relative to snu-mllab/KVzip).
 """

@@ -172,3 +172,31 @@ def test_varlen_attn_matches_dense_masked_identity():
     a = orc.varlen_attn(q, flat_k, flat_v, starts, lens, q_len, causal=True)
     b = orc.dense_masked_attn(q, k, v, keep, q_len)
     assert torch.allclose(a.float(), b.float(), atol=1e-3, rtol=0)
+
+
+def test_varlen_attn_matches_torch_sdpa():
+    """a13, second anchor: an INDEPENDENT implementation of the published semantics of flash_attn_varlen_func(causal=True)
+    (scaled dot-product attention per packed sequence, causal mask aligned to the bottom-right corner when seqlen_q <
+    seqlen_k).  flash-attn itself is a third-party dependency that is absent from /root/reference (parity unpinned at that
+    boundary); torch's math-backend SDPA with an explicit mask is what is available here."""
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    Hkv, G, D = 3, 7, 128
+    for q_len in (1, 4):
+        lens = [37, 5 + q_len, 64]
+        starts = [0, 40, 40 + 5 + q_len + 3]          # segments with gaps between them, as in the slack layout
+        total = starts[-1] + lens[-1]
+        k = torch.randn(total, D).half()
+        v = torch.randn(total, D).half()
+        q = torch.randn(Hkv * q_len, G, D).half()      # [Hkv*q_len, G, D] as handed over by prepare()
+        got = orc.varlen_attn(q, k, v, starts, lens, q_len, causal=True).float()
+        for h in range(Hkv):
+            kh = k[starts[h]:starts[h] + lens[h]].float()
+            vh = v[starts[h]:starts[h] + lens[h]].float()
+            qh = q[h * q_len:(h + 1) * q_len].float().transpose(0, 1)          # [G, q_len, D]
+            i = torch.arange(q_len).view(-1, 1)
+            j = torch.arange(lens[h]).view(1, -1)
+            mask = j <= i + (lens[h] - q_len)                                   # bottom-right aligned causal mask
+            want = F.scaled_dot_product_attention(qh.unsqueeze(0), kh.expand(1, G, -1, -1), vh.expand(1, G, -1, -1),
+                                                  attn_mask=mask).squeeze(0).transpose(0, 1)   # [q_len, G, D]
+            assert torch.allclose(got[h * q_len:(h + 1) * q_len], want, atol=2e-3, rtol=0)

@@ -10,7 +10,7 @@ def rep(s, old, new):
     return s.replace(old, new)
 
 def nofrag(s):
-    return rep(s, "            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], pbuf, kb + 1);",
+    return rep(s, "            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);",
                "            if (kb + 1 < SC_TILE / 32) { for (int kk = 0; kk < C::KK; ++kk) fr[(kb + 1) & 1][kk] = fr[kb & 1][kk] + 1u; }")
 def nostage(s):
     return rep(s, "        if (linear) stage_tile_linear<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);\n        else stage_keys_gather",
@@ -20,13 +20,14 @@ def noepi(s):
     b = s.index("        l_run[g] += ps0 + ps1;  // (masked keys")
     return s[:a] + "        float ps0 = acc[0], ps1 = acc[7];\n" + s[b:]
 def nomfma(s):
-    s = rep(s, "                    acc0 = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[0][kk], acc0);\n                    acc1 = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[1][kk], acc1);",
-            "                    acc0[2 * kk] += __builtin_bit_cast(float, fr[kb & 1][kk][0]); acc0[2 * kk + 1] += __builtin_bit_cast(float, fr[kb & 1][kk][1]);\n                    acc1[2 * kk] += __builtin_bit_cast(float, fr[kb & 1][kk][2]); acc1[2 * kk + 1] += __builtin_bit_cast(float, fr[kb & 1][kk][3]);")
-    return s
+    return rep(s, "                    if (!skip[g]) acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);",
+               "                    if (!skip[g]) { acc[g][2 * kk] += __builtin_bit_cast(float, fr[kb & 1][kk][0]); acc[g][2 * kk + 1] += __builtin_bit_cast(float, fr[kb & 1][kk][1]); }")
 def nobarrier(s):
     return rep(s, "        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more", "        // (no barrier)")
 variants = {"base": lambda s: s, "nofrag": nofrag, "nostage": nostage, "noepi": noepi, "nomfma": nomfma, "nobarrier": nobarrier,
-            "noepi_nomfma": lambda s: nomfma(noepi(s)), "nofrag_nostage": lambda s: nostage(nofrag(s))}
+            "noepi_nomfma": lambda s: nomfma(noepi(s)), "nofrag_nostage": lambda s: nostage(nofrag(s)),
+            "compute_only": lambda s: nobarrier(nostage(nofrag(s))), "mfma_only": lambda s: noepi(nobarrier(nostage(nofrag(s)))),
+            "epi_only": lambda s: nomfma(nobarrier(nostage(nofrag(s))))}
 def trace(s):
     """Light in-kernel timeline of pass A: three s_memtime stamps per tile (tile start, arrival at the hand-over barrier,
     release from it), consumed only at the end of the tile so that the fragment prefetch is not disturbed."""
