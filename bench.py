@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--sink", type=int, default=32)
     ap.add_argument("--decode-tokens", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-unfused", action="store_true", help="decode with update / prepare / attend as three calls")
     ap.add_argument("--q-pool", type=int, default=0, help="distinct chunk inputs kept in HBM (0 = all chunks)")
     ap.add_argument("--prof-period", type=int, default=16,
                     help="every n-th scoring call of the timed region runs alone on the caller's stream with its kernels "
@@ -229,9 +230,12 @@ def main():
     def decode_tokens(n):
         for _ in range(n):
             for l in range(L):
-                kf, vf = kv.update(kd[l], vd[l], l)
-                qf, kf, vf, info = kv.prepare(qd[l], kf, vf, l)
-                kv.attend(qf, kf, vf, info)
+                if args.decode_unfused:
+                    kf, vf = kv.update(kd[l], vd[l], l)
+                    qf, kf, vf, info = kv.prepare(qd[l], kf, vf, l)
+                    kv.attend(qf, kf, vf, info)
+                else:  # what kvzip_amd/attn.py does for a generation step: append + attention in one launch
+                    kv.update_attend(qd[l], kd[l], vd[l], l)
     seen = kv._seen_tokens
     decode_tokens(2)
     torch.cuda.synchronize()

@@ -196,6 +196,21 @@ int kvz_varlen_attn(const void* q, const void* k, const void* v,
                     float scale, int causal, int dtype,
                     void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
 
+/* a10 + a13 fused (decode step, one new token):  kvz_append_inplace(t = 1) followed by kvz_varlen_attn(q_len = 1) in ONE
+ * launch of the split kernel (+ the combine kernel).  Replaces the pair
+ *   past_key_value.update(...)   reference attention/attn.py:44-48  -> csrc/csrc/cuda_api.cu:68-111
+ *   flash_attn_varlen_func(...)  reference attention/attn.py:61-71
+ * for the generation loop.  k_state / v_state: [Hkv, 1, D] views (head stride in elements, D contiguous).  The row is
+ * written at  k_start[h] + k_len[h] + k_len_offset  (k_len_offset = tokens appended before this call) and the attention
+ * runs over k_len[h] + k_len_offset + 1 keys; max_len_k must cover that.  Results are bit-identical to the two-call
+ * sequence. */
+int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache,
+                           const void* k_state, const void* v_state,
+                           int64_t k_state_head_stride, int64_t v_state_head_stride,
+                           const int32_t* k_start, const int32_t* k_len, int k_len_offset,
+                           int Hkv, int G, int D, int max_len_k, float scale, int dtype,
+                           void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

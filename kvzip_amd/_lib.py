@@ -38,6 +38,8 @@ SIGNATURES = {
     "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz,
+                                    _vp]),
 }
 
 _lib = None

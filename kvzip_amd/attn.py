@@ -5,6 +5,7 @@ interface registry).  Hooks on the cache object, in this order (attention/attn.p
     update()      append the new K,V                                   (always)
     _get_score()  KV importance of the current scoring chunk           (if cache.get_score)
     prepare()+attend()  variable-length attention over the pruned KV   (if cache.pruned)
+    update_attend()     the three of them in one launch                (generation step on a pruned slack-layout cache)
 
 The dense (pre-prune) attention is NOT on the eviction hot path; the reference delegates it to flash-attn's dense
 kernel (attention/attn.py:75-89).  Here it goes through torch SDPA, registered as the attention implementation
@@ -61,6 +62,13 @@ def llama_qwen_attn_forward(self, hidden_states: torch.Tensor,
     query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
 
     kv = past_key_values
+    # generation step on a pruned slack-layout cache: update + prepare + attend in one launch (bit-identical result)
+    if (q_len == 1 and getattr(kv, "pruned", None) and not getattr(kv, "get_score", None)
+            and getattr(kv, "layout", None) == "slack" and hasattr(kv, "update_attend")):
+        attn = kv.update_attend(query_states, key_states, value_states, self.layer_idx, softmax_scale=self.scaling)
+        n_kv = self.config.num_key_value_heads
+        attn_output = attn.view(bsz, n_kv, q_len, -1, self.head_dim).transpose(1, 2).reshape(bsz, q_len, -1).contiguous()
+        return self.o_proj(attn_output), None
     if kv is not None:
         key_states, value_states = kv.update(key_states, value_states, self.layer_idx)
 

@@ -48,11 +48,15 @@ template <int D> struct AttnCfg {
     static constexpr int VLOADS = AT_KT * CPR / WAVE;       // 16-byte V loads per lane per tile
 };
 
-template <typename T, int D>
+// APPEND: the decode step's O(1) cache append is done by this kernel.  k_len_offset already counts the new token; the
+// block(s) that own the last key range of a head first copy the new K and V row of that head from the state tensors into
+// the cache (row k_start[h] + len - 1) and then read it back like any other key (no other block touches that row).
+template <typename T, int D, bool APPEND>
 __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
-    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const int32_t* __restrict__ k_start,
+    const T* __restrict__ q, const T* k, const T* v, const int32_t* __restrict__ k_start,
     const int32_t* __restrict__ k_len, int k_len_offset, int G, int q_len, int chunk, float scale, int causal,
-    float* __restrict__ part_o, float* __restrict__ part_ml, int n_splits, int n_rtiles) {
+    float* __restrict__ part_o, float* __restrict__ part_ml, int n_splits, int n_rtiles,
+    const T* __restrict__ k_new, const T* __restrict__ v_new, int64_t kn_head_stride, int64_t vn_head_stride) {
     typedef AttnCfg<D> C;
     typedef typename HalfTraits<T>::v8 v8;
     const int split = blockIdx.x, h = blockIdx.y, rt = blockIdx.z;
@@ -60,6 +64,17 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     const int c0 = split * chunk;
     if (c0 >= len) return;
     const int c1 = min(len, c0 + chunk);
+    if (APPEND && c1 == len) {
+        constexpr int CH = D * 2 / 16;  // 16-byte chunks per row
+        if ((int)threadIdx.x < 2 * CH) {
+            const bool is_v = (int)threadIdx.x >= CH;
+            const int c = (int)threadIdx.x - (is_v ? CH : 0);
+            const char* src = reinterpret_cast<const char*>(is_v ? v_new + h * vn_head_stride : k_new + h * kn_head_stride) + c * 16;
+            char* dst = const_cast<char*>(reinterpret_cast<const char*>(is_v ? v : k)) + ((int64_t)k_start[h] + len - 1) * (D * 2) + c * 16;
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+        }
+        __syncthreads();  // (workgroup-scope release/acquire: the row is visible to the loads of this block below)
+    }
     const int R = q_len * G;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -314,16 +329,24 @@ static inline int attn_chunk(int Hkv, int max_len_k) {
 template <typename T, int D>
 static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len,
                        int k_len_offset, int Hkv, int G, int q_len, int max_len_k, float scale, int causal, void* out, void* ws,
-                       hipStream_t stream) {
+                       hipStream_t stream, const void* k_new = nullptr, const void* v_new = nullptr, int64_t kn_stride = 0,
+                       int64_t vn_stride = 0) {
     const int chunk = attn_chunk(Hkv, max_len_k);
     const int n_splits = (max_len_k + chunk - 1) / chunk > 0 ? (max_len_k + chunk - 1) / chunk : 1;
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
     float* part_o = reinterpret_cast<float*>(ws);
     float* part_ml = part_o + (size_t)Hkv * n_rtiles * n_splits * AT_RT * D;
     ProfScope ps("varlen_attn", stream);  // split + combine
-    hipLaunchKernelGGL((varlen_attn_split_kernel<T, D>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
-                       reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
-                       k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles);
+    if (k_new)
+        hipLaunchKernelGGL((varlen_attn_split_kernel<T, D, true>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
+                           reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
+                           k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles,
+                           reinterpret_cast<const T*>(k_new), reinterpret_cast<const T*>(v_new), kn_stride, vn_stride);
+    else
+        hipLaunchKernelGGL((varlen_attn_split_kernel<T, D, false>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
+                           reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
+                           k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles,
+                           (const T*)nullptr, (const T*)nullptr, (int64_t)0, (int64_t)0);
     KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
     hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles, AT_RT), dim3(CB_THREADS), 0, stream, part_o,
                        part_ml, k_len, k_len_offset, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
@@ -363,4 +386,29 @@ extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, cons
     }
     if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
     return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+}
+
+extern "C" int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache, const void* k_state, const void* v_state,
+                                      int64_t k_state_head_stride, int64_t v_state_head_stride, const int32_t* k_start,
+                                      const int32_t* k_len, int k_len_offset, int Hkv, int G, int D, int max_len_k,
+                                      float scale, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(q && k_cache && v_cache && k_state && v_state && k_start && k_len && out && ws, KVZ_EINVAL,
+                "kvz_varlen_attn_append: null pointer");
+    KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && max_len_k >= 1 && k_len_offset >= 0, KVZ_EINVAL, "kvz_varlen_attn_append: bad shape");
+    KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_varlen_attn_append: head_dim %d unsupported (64 or 128)", D);
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_varlen_attn_append: bad dtype %d", dtype);
+    KVZ_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(k_state) && aligned16(v_state), KVZ_EINVAL,
+                "kvz_varlen_attn_append: pointers must be 16-byte aligned");
+    KVZ_REQUIRE((k_state_head_stride * 2) % 16 == 0 && (v_state_head_stride * 2) % 16 == 0, KVZ_EINVAL,
+                "kvz_varlen_attn_append: state head strides must be multiples of 8 elements");
+    KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, 1, D, max_len_k), KVZ_EWORKSPACE,
+                "kvz_varlen_attn_append: workspace too small");
+    const int off = k_len_offset + 1;  // the keys attended to include the token appended by this call
+    if (dtype == KVZ_F16) {
+        if (D == 128) return launch_attn<_Float16, 128>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+        return launch_attn<_Float16, 64>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    }
+    if (D == 128) return launch_attn<__bf16, 128>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    return launch_attn<__bf16, 64>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
 }

@@ -346,6 +346,35 @@ class EvictCache(_CacheBase):
                                k_len_offset=info["k_len_offset"])
 
 
+    def update_attend(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int,
+                      softmax_scale: Optional[float] = None) -> torch.Tensor:
+        """Decode step (one new token) on the pruned cache, slack layout: ``update`` + ``prepare`` + ``attend`` in one
+        launch of the attention kernel, which also writes the token's K, V row into the slack of every head.
+        query ``[1, H, 1, D]``, key / value ``[1, Hkv, 1, D]``; returns ``[Hkv, G, D]`` like ``attend``.  The cache
+        bookkeeping (``_seen_tokens``, ``info["offset"]``) ends up exactly as after the three separate calls."""
+        assert self.info["flatten"] and self.layout == "slack" and query_states.shape[-2] == 1
+        if layer_idx == 0:
+            self._seen_tokens += 1
+        off = self.info["offset"][layer_idx]
+        if off + 1 > self.slack:
+            self._grow_slack(off + 1)
+        dim = query_states.shape[-1]
+        max_len_k = self.info["max_len_k"][layer_idx] + off + 1
+        key = getattr(self, "_attn_ws_key", None)
+        if self._attn_ws is None or key is None or key[0] != 1 or max_len_k > key[1]:
+            cap = max_len_k + 4096
+            lib = ops._lib.load()
+            need = max(lib.kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, 1, dim, n) for n in (max_len_k, cap))
+            self._attn_ws = torch.empty(2 * int(need) + 256, dtype=torch.uint8, device=query_states.device)
+            self._attn_ws_key = (1, cap)
+        out = ops.varlen_attn_append(query_states.reshape(-1, self.n_group_kv, dim), self.key_cache[layer_idx],
+                                     self.value_cache[layer_idx], key_states, value_states,
+                                     self.info["seg_start"][layer_idx], self.info["len_k"][layer_idx], off, max_len_k,
+                                     softmax_scale=softmax_scale, workspace=self._attn_ws)
+        self.info["offset"][layer_idx] = off + 1
+        return out
+
+
 class RetainCache(_CacheBase):
     """KV cache that keeps the full KV in memory and subsamples it at every attention call, so that several
     compression ratios can be evaluated from a single prefill (reference attention/kvcache.py:216-347).

@@ -269,6 +269,30 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
     return out
 
 
+def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.Tensor,
+                       v_state: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor, k_len_offset: int, max_len_k: int,
+                       softmax_scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode step in one launch: append the new token's K, V (``[1, Hkv, 1, D]``, any head stride) to the per-head slack
+    of the flat cache and attend ``q`` (``[Hkv, G, D]``) over ``k_len + k_len_offset + 1`` keys.  ``k_len_offset`` counts the
+    tokens appended BEFORE this call.  Bit-identical to ``append_inplace`` followed by ``varlen_attn``."""
+    lib = _lib.load()
+    Hkv, G, D = q.shape
+    assert k_state.shape[-3] == Hkv and k_state.shape[-2] == 1 and v_state.shape[-2] == 1
+    assert k_state.stride(-1) == 1 and v_state.stride(-1) == 1 and q.is_contiguous()
+    assert k_start.dtype == torch.int32 and k_len.dtype == torch.int32
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    out = torch.empty_like(q)
+    if workspace is None:
+        need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, 1, D, int(max_len_k))
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    rc = lib.kvz_varlen_attn_append(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(),
+                                    v_state.data_ptr(), k_state.stride(-3), v_state.stride(-3), k_start.data_ptr(),
+                                    k_len.data_ptr(), int(k_len_offset), Hkv, G, D, int(max_len_k), float(scale),
+                                    _dtype_code(q.dtype), out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
+    check(rc, "kvz_varlen_attn_append")
+    return out
+
+
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
                            softmax_scale=None, causal=False, seqused_k=None):
     """Call-compatible stand-in for the reference's use of ``flash_attn.flash_attn_varlen_func``

@@ -228,3 +228,44 @@ def test_async_scoring_equals_single_stream():
         s2, t2, v2 = run(2)
         assert torch.equal(s1.view(torch.int16), s2.view(torch.int16))
         assert t1 == t2 and torch.equal(v1, v2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_update_attend_equals_update_prepare_attend(dtype):
+    """The fused generation step (append + attention in one launch) against the three separate calls: attention outputs,
+    cache rows and bookkeeping must be bit-identical, over enough tokens to cross split boundaries."""
+    from kvzip_amd.kvcache import EvictCache
+    L, H, Hkv, D, sink, N = 3, 14, 2, 128, 8, 1500
+    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    g = torch.Generator(device=DEV).manual_seed(31)
+
+    def make():
+        gg = torch.Generator(device=DEV).manual_seed(5)
+        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dtype, verbose=False, slack=64)
+        for l in range(L):
+            kv.update(torch.randn(1, Hkv, sink + N, D, generator=gg, device=DEV).to(dtype),
+                      torch.randn(1, Hkv, sink + N, D, generator=gg, device=DEV).to(dtype), l)
+        kv.score = [torch.rand(1, Hkv, N, generator=gg, device=DEV).to(dtype) for _ in range(L)]
+        kv.prune(0.35)
+        return kv
+
+    a, b = make(), make()
+    for step in range(70):  # more than the initial slack: also exercises _grow_slack on both paths
+        for l in range(L):
+            q = torch.randn(1, H, 1, D, generator=g, device=DEV).to(dtype)
+            # K after RoPE / V out of the projection are strided views in the real forward pass
+            kk = torch.randn(1, 1, Hkv, D, generator=g, device=DEV).to(dtype).transpose(1, 2)
+            vv = torch.randn(1, 1, Hkv, D, generator=g, device=DEV).to(dtype).transpose(1, 2)
+            kf, vf = a.update(kk, vv, l)
+            qf, kf, vf, info = a.prepare(q, kf, vf, l)
+            want = a.attend(qf, kf, vf, info)
+            got = b.update_attend(q, kk, vv, l)
+            assert torch.equal(want.view(torch.int16), got.view(torch.int16)), (step, l)
+    assert a._seen_tokens == b._seen_tokens and a.info["offset"] == b.info["offset"]
+    for l in range(L):
+        seg = a.info["seg_start"][l].tolist()
+        lens = (a.info["len_k"][l] + a.info["offset"][l]).tolist()
+        assert a.info["seg_start"][l].tolist() == b.info["seg_start"][l].tolist()
+        for h in range(Hkv):
+            assert torch.equal(a.key_cache[l][seg[h]:seg[h] + lens[h]], b.key_cache[l][seg[h]:seg[h] + lens[h]])
+            assert torch.equal(a.value_cache[l][seg[h]:seg[h] + lens[h]], b.value_cache[l][seg[h]:seg[h] + lens[h]])
