@@ -67,6 +67,39 @@ extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
 """
     return s
 variants["gantt"] = gantt
+def prio(s):
+    """raise the wave priority while the matrix chain is issued (pass A and pass B)"""
+    s = rep(s, """            __builtin_amdgcn_sched_barrier(0);
+            // the chains of different row groups are independent and are issued ALTERNATELY""", """            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+            // the chains of different row groups are independent and are issued ALTERNATELY""")
+    s = rep(s, """            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
+            else turnover();
+            __builtin_amdgcn_sched_barrier(0);""", """            __builtin_amdgcn_s_setprio(0);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
+            else turnover();
+            __builtin_amdgcn_sched_barrier(0);""")
+    s = rep(s, """#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[kk]), acc);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);""", """            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[kk]), acc);
+            __builtin_amdgcn_s_setprio(0);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);""")
+    return s
+variants["prio"] = prio
+def prio_epi(s):
+    """the opposite: raise the priority during the VALU epilogue"""
+    s = rep(s, """            else turnover();
+            __builtin_amdgcn_sched_barrier(0);
+            auto epi = """, """            else turnover();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+            auto epi = """)
+    s = rep(s, """            if constexpr (PA_RG > 1) epi(std::integral_constant<int, PA_RG - 1>{});""", """            if constexpr (PA_RG > 1) epi(std::integral_constant<int, PA_RG - 1>{});
+            __builtin_amdgcn_s_setprio(0);""")
+    return s
+variants["prio_epi"] = prio_epi
 variants["pb8x4"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 8\n#define KVZ_PB_OCC 4")
 variants["pb4x3"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 3")
 variants["pb8x2"] = lambda s: rep(s, "#define KVZ_PB_WAVES 4\n#define KVZ_PB_OCC 2", "#define KVZ_PB_WAVES 8\n#define KVZ_PB_OCC 2")
