@@ -333,6 +333,27 @@ def test_score_chunk_edge_shapes(H, Hkv, D, sink, N, start, m, q_len):
     assert torch.equal(got.view(torch.int16), again.view(torch.int16))
 
 
+def test_score_chunk_fuzz_small_shapes_vs_oracle():
+    """60 random small shapes (both dtypes, both head dims, G and Hkv from 1 to 8, windows with gaps, 1..400 ctx keys and query
+    rows) against the CPU oracle.  Complements tools/fuzz_score.py, which sweeps large shapes against a second build."""
+    import random
+    rng = random.Random(2024)
+    g = torch.Generator().manual_seed(99)
+    for n in range(60):
+        Hkv, G, D = rng.choice([1, 2, 3, 8]), rng.choice([1, 2, 4, 7]), rng.choice([64, 128])
+        dtype = torch.bfloat16 if rng.random() < 0.3 else torch.float16
+        sink, m, q_len = rng.choice([0, 1, 16, 30]), rng.randint(1, 400), rng.randint(1, 400)
+        start = sink + rng.randint(0, 150)
+        klen = start + m + rng.randint(0, 150) + q_len
+        q = torch.randn(1, Hkv * G, q_len, D, generator=g).to(dtype)
+        k = torch.randn(1, Hkv, klen, D, generator=g).to(dtype)
+        want = orc.get_score(q, k, sink, start, start + m)
+        got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, start, start + m).cpu()
+        d = ulp_diff(got, want)
+        frac = float((d == 0).float().mean())
+        assert int(d.max()) <= 8 and (frac >= 0.97 or d.numel() < 200), (n, Hkv, G, D, dtype, sink, start, m, q_len, frac, int(d.max()))
+
+
 @pytest.mark.parametrize("shape", [(14, 2, 64, 30, 2048, 30, 2030, 2013), (28, 4, 128, 32, 8192, 4032, 6032, 2026),
                                    (32, 8, 128, 32, 3000, 732, 2732, 2026), (8, 2, 128, 16, 900, 16, 916, 37)])
 def test_score_chunk_is_deterministic(shape):
