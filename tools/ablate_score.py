@@ -67,6 +67,10 @@ extern "C" int kvz_debug_read_trace(unsigned long long* host, size_t bytes) {
 """
     return s
 variants["gantt"] = gantt
+variants["fragafter"] = lambda s: rep(s, """            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
+            else turnover();""", """            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
+            else turnover();""")
 def prio(s):
     """raise the wave priority while the matrix chain is issued (pass A and pass B)"""
     s = rep(s, """            __builtin_amdgcn_sched_barrier(0);
