@@ -14,6 +14,8 @@
 //   ds_read_b64_tr_b16.  A second small kernel merges the per-split partials.
 #include "kvz_common.h"
 
+#include <stdlib.h>
+
 namespace kvz {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -318,9 +320,22 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const f
     }
 }
 
+static inline int attn_items() {
+    static int items = 0;
+    if (!items) {
+        const char* e = getenv("KVZ_ATTN_ITEMS");  // tuning knob (work items the key ranges are cut into)
+        items = e ? atoi(e) : 256;
+        if (items < 1) items = 256;
+    }
+    return items;
+}
 static inline int attn_chunk(int Hkv, int max_len_k) {
-    // aim for ~512 (head, chunk) work items (2 blocks per CU); chunk is a multiple of one block-iteration (128 keys)
-    int64_t c = ((int64_t)Hkv * max_len_k + 511) / 512;
+    // aim for ~256 (head, chunk) work items = one per CU; chunk is a multiple of one block-iteration (128 keys).  The kernel
+    // is latency-bound per block (Q fragments, first tile), so fewer and longer key streams win over a second resident
+    // block per CU: 256 -> 1066 tokens/s, 512 -> 984, 1024 -> 919 on the headline cache (ragged heads leave fewer items
+    // than the target anyway).
+    const int items = attn_items();
+    int64_t c = ((int64_t)Hkv * max_len_k + items - 1) / items;
     c = (c + 127) / 128 * 128;
     if (c < 128) c = 128;
     return (int)c;
