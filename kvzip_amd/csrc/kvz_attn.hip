@@ -6,7 +6,7 @@
 //
 // Decode (q_len = 1) is HBM-bound: every kept K and V row is read exactly once per generated token.
 // Design: split-K "flash decoding".
-//   grid = (splits, Hkv, row tiles of 16 query rows); a block owns one key chunk of one head, its 4
+//   grid = (splits, Hkv, row tiles of 16 query rows); a block owns one key chunk of one head, its 8
 //   waves stride over 32-key tiles of the chunk.
 //   S^T = K.Q^T on v_mfma_f32_16x16x32 with K rows loaded straight from HBM as the A operand (16-byte
 //   contiguous per lane, no LDS); softmax state lives in registers (lane = one query row);
@@ -35,8 +35,8 @@ template <> struct HalfTraits<__bf16> {
     __device__ static inline f4 mfma(v8 a, v8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int AT_THREADS = 256;
-constexpr int AT_WAVES = 4;
+constexpr int AT_THREADS = 512;
+constexpr int AT_WAVES = 8;
 constexpr int AT_KT = 32;           // keys per wave-tile
 constexpr int AT_RT = 16;           // query rows per block (MFMA N)
 
