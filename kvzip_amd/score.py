@@ -24,18 +24,58 @@ import torch
 from . import ops
 
 
-# Side streams are shared by all cache objects of a process: HIP spreads streams over a handful of hardware queues
-# (4 by default) in creation order, and two streams that land on the same queue do not overlap at all - which is what
-# happened when every cache object created its own pair.
+# Side streams are shared by all cache objects of a process and are CHOSEN BY MEASUREMENT: HIP maps streams onto a handful of
+# hardware queues (4 by default) in a way the API does not expose, and two streams that land on the same queue do not
+# overlap at all (observed: every other freshly created pair).  Candidates of both priorities are created once and a pair is
+# accepted when two spin kernels launched on it really run concurrently.
 _SIDE_STREAMS = {}
 
 
+def _overlaps(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 400_000) -> bool:
+    """True if spin kernels on the two streams run concurrently (wall time well below twice one kernel)."""
+    def timed(streams):
+        torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1)
+    timed([a])  # warm-up (first launch on a stream creates its queue)
+    timed([b])
+    one = min(timed([a]), timed([b]))
+    both = timed([a, b])
+    return both < 1.5 * one
+
+
 def _side_streams(device, n: int):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    pool = _SIDE_STREAMS.setdefault(key, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
-    return pool[:n]
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _SIDE_STREAMS.get(key)
+    if pool is not None and len(pool) >= n:
+        return pool[:n]
+    with torch.cuda.device(key):
+        cands = [torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1)]
+        cands += [torch.cuda.Stream(device=dev) for _ in range(4)]
+        chosen = []
+        try:
+            for c in cands:
+                if all(_overlaps(c, o) for o in chosen):
+                    chosen.append(c)
+                if len(chosen) >= n:
+                    break
+        except Exception:  # no spin kernel in this build: take the candidates as they come
+            chosen = cands[:n]
+        while len(chosen) < n:  # fewer independent queues than requested: the extra streams simply do not overlap
+            chosen.append(chosen[-1] if chosen else cands[0])
+    _SIDE_STREAMS[key] = chosen
+    return chosen[:n]
 
 
 class KVScore:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""How much does running the (independent) scoring calls of consecutive layers on TWO streams buy?  Tails of the persistent
-kernels, launch gaps and the tiny merge / finalize kernels of one call overlap with the big kernels of the other."""
+"""How much does running the (independent) scoring calls of consecutive layers on TWO streams buy, and does it depend on
+how the side streams were created?  HIP maps streams onto a few hardware queues; two streams on one queue do not overlap.
+   python tools/overlap_probe.py [n_dummy_streams_created_first]"""
 import os
 import sys
 import time
@@ -20,17 +21,25 @@ K = [torch.randn(1, Hkv, sink + 8192 + q_len, D, generator=g, device=dev).half()
 start = sink + 4000
 outs = [torch.empty(1, Hkv, m, dtype=torch.float16, device=dev) for _ in range(L)]
 need = 64 << 20
-for nstreams in (1, 2, 3, 4, 1, 2):
-    streams = [torch.cuda.Stream() for _ in range(nstreams)]
-    ws = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+dummies = [torch.cuda.Stream() for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 0)]
+
+
+def run(streams, label):
+    ws = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in streams]
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for it in range(6):
             for l in range(L):
-                s = l % nstreams
-                with torch.cuda.stream(streams[s]):
-                    ops.score_chunk(Q[l], K[l], sink, start, start + m, out=outs[l], workspace=ws[s])
+                s = l % len(streams)
+                ops.score_chunk(Q[l], K[l], sink, start, start + m, out=outs[l], workspace=ws[s], stream=streams[s])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(f"{nstreams} stream(s): {dt / (6 * L) * 1e6:.1f} us per score_chunk call")
+    print(f"{label}: {dt / (6 * L) * 1e6:.1f} us per score_chunk call")
+
+
+run([torch.cuda.current_stream()], "1 stream (current)")
+for trial in range(4):
+    run([torch.cuda.Stream(), torch.cuda.Stream()], f"2 default-priority streams (trial {trial})")
+run([torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)], "high + normal priority")
+run([torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)], "high + high priority")
