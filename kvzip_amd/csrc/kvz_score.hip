@@ -18,7 +18,8 @@
 // (reduction over keys = over registers, lane-local); pass B streams query rows and keeps 16 running
 // per-key maxima per lane that are reduced across lanes once at the end.  LDS tiles are XOR-swizzled on
 // 16-byte chunks so that ds_read_b128 fragment reads are bank-conflict free.
-// Bound: VALU issue of the rounding chain (MFMA and VALU do not overlap on a SIMD).
+// Bound: SIMD issue - the matrix pipe and the VALU rounding chain share one in-order issue port and barely overlap
+// (profiles/r1_score_timeline.txt).
 #include "kvz_common.h"
 
 #include <math.h>
@@ -43,7 +44,7 @@ template <> struct Mfma32<__bf16> {
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int SC_TILE = 128;     // streamed rows per LDS tile (2 x 32 KiB LDS buffers per block -> 2 blocks per CU)
+constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
 #ifndef KVZ_PB_WAVES
 #define KVZ_PB_WAVES 4
 #define KVZ_PB_OCC 2
@@ -53,8 +54,8 @@ constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget i
 #ifndef KVZ_KSPLIT_TILES
 #define KVZ_KSPLIT_TILES 4
 #endif
-constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;
-constexpr int SC_PERSISTENT_BLOCKS = 256;  // pass A: one persistent block per CU  // pass A: key tiles per block (load balance under the causal mask)
+constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;  // pass A: key tiles per work item (4: 2 -> +9 % item switches, 8 -> +6 % imbalance)
+constexpr int SC_PERSISTENT_BLOCKS = 256;          // pass A: one persistent block per CU
 
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
