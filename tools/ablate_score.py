@@ -131,6 +131,9 @@ def split2(s):
             for (int g = 0; g < PA_RG; ++g) acc[g] += acc2[g];""")
 variants["split2"] = split2
 variants["w4rg2"] = lambda s: rep(s, "#define KVZ_PA_WAVES 8\n#define KVZ_PA_RG 1", "#define KVZ_PA_WAVES 4\n#define KVZ_PA_RG 2")
+variants["ks3"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 3")
+variants["ks5"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 5")
+variants["ks6"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 6")
 variants["ks2"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 2")
 variants["ks8"] = lambda s: rep(s, "#define KVZ_KSPLIT_TILES 4", "#define KVZ_KSPLIT_TILES 8")
 os.makedirs(os.path.join(ROOT, "tools/ab"), exist_ok=True)
