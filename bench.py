@@ -303,7 +303,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma", "kernel": dominant, "achieved": dom_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": pmc.get(dominant, {}).get("traffic_bytes"),
             "note": ("algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) launch (QK^T only, SURVEY §8d); "
                      "score_combined = same flops over rowstat+colmax time; kernel durations from hipEvents on the launch "
                      f"stream inside the timed region: every {max(1, args.prof_period)}th scoring call runs alone on the caller's "
