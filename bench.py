@@ -2,12 +2,16 @@
 """bench.py — KV tokens scored+pruned per second at a 128k-token context, ratio 0.3 (BASELINE.json metric).
 
 One "step" = one full pass of the eviction hot path over one synthetic context that is already resident in HBM:
-    66 scoring chunks x 28 layers of  update(repeat K,V) -> _get_score   (attention/score.py:36-65)
-    -> global-threshold selection (score.py:88-102) -> compaction of all layers (kvcache.py:152-185)
-driven through the drop-in cache object (kvzip_amd.EvictCache).  Weak scaling: every rank (one per GPU) owns
-one independent context; there is no data-path collective, only a gather of the tiny per-context result record.
+    --level pair (default, BASELINE configs C2/C3/C4):
+        ceil(N/2000) scoring chunks x L layers of  update(repeat K,V) -> _get_score   (attention/score.py:36-65)
+        -> global-threshold selection (score.py:88-102) -> compaction of all layers (kvcache.py:152-185)
+    --level head (BASELINE config C5, context-independent eviction, model/wrapper.py:40-58):
+        head scores [L,Hkv] (the reference's utils/head_score values) -> head-level selection -> compaction of all layers
+driven through the drop-in cache object (kvzip_amd.EvictCache), followed (untimed for `value`) by post-prune decode steps.
+Weak scaling: every rank (one per GPU) owns one independent context; there is no data-path collective, only the gather of
+the per-context result record (kvzip_amd.dist.gather_results) inside the timed region.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1 without a launcher: spawns one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -19,6 +23,7 @@ import ctypes as C
 import json
 import math
 import os
+import socket
 import sys
 import time
 import types
@@ -38,14 +43,16 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="qwen2.5-7b", choices=sorted(GEOM))
     ap.add_argument("--ctx", type=int, default=131072)
-    ap.add_argument("--ratio", type=float, default=0.3)
+    ap.add_argument("--ratio", type=float, default=None, help="keep ratio (default 0.3; 0.6 with --level head)")
+    ap.add_argument("--level", default="pair", choices=["pair", "head"],
+                    help="pair: score + global threshold (C2-C4); head: context-independent head-level eviction (C5)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--chunk", type=int, default=2000)       # model/wrapper.py:200
     ap.add_argument("--sink", type=int, default=32)
@@ -58,75 +65,191 @@ def parse():
                          "bracketed by hipEvents (kernel durations for the roofline); the others overlap on the side streams")
     ap.add_argument("--score-streams", type=int, default=2,
                     help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.ratio is None:
+        args.ratio = 0.6 if args.level == "head" else 0.3
+    return args
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# rank logic (one process per GPU).  Backend-agnostic on purpose: tests/test_dist_gloo.py runs exactly this code with
+# world_size 2 over gloo on CPU.
+# ---------------------------------------------------------------------------------------------------------------
+class Ranks:
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run or our own spawn)."""
+
+    def __init__(self, expected_world: int, backend: str = "nccl", device=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != expected_world:
+            raise SystemExit(f"--gpus {expected_world} but WORLD_SIZE={self.world}")
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def barrier(self, sync=None):
+        if self.dist is not None:
+            self.dist.barrier()
+        if sync is not None:
+            sync()
+
+    def max_over_ranks(self, seconds: float, device="cpu") -> float:
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_records(self, thres: float, r_real: float, len_k: torch.Tensor, layers: int, Hkv: int):
+        """The only exchange the path has: one fixed-size record per context (= per rank), library gather."""
+        from kvzip_amd.dist import gather_results, pack_record
+        return gather_results([pack_record(thres, r_real, len_k)], self.world, layers, Hkv)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawned(local_rank: int, world: int, port: int, argv, entry):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    entry(argv)
+
+
+def launch(argv, entry, gpus: int):
+    """`python bench.py --gpus N` without torchrun: spawn one process per GPU (rank = local rank) and run `entry` in each."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return entry(argv)
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned, args=(gpus, _free_port(), argv, entry), nprocs=gpus, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def prof_read(lib, name):
     t, c = C.c_double(0), C.c_int64(0)
     lib.kvz_prof_read(name.encode(), C.byref(t), C.byref(c))
     return t.value, c.value
 
 
-def cpu_baseline(L, H, Hkv, D, sink, N, chunk, dtype, ratio):
-    """Oracle (CPU restatement of the reference path, validated bit-for-bit against the reference's golden
-    vectors) timed on this box's host cores on a bounded sample of the same workload."""
+def ulp_keys(t: torch.Tensor) -> torch.Tensor:
+    x = t.detach().cpu().contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    return torch.where(x >= 0x8000, 0x8000 - (x - 0x8000) - 1, x + 0x8000)
+
+
+def head_scores_for(model: str, L: int, Hkv: int, dtype) -> torch.Tensor:
+    """[L,Hkv] head scores: the reference's own utils/head_score values (fixture tests/golden/g4_head_score.npz) for the
+    models it ships them for, seeded random values otherwise."""
+    import numpy as np
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "g4_head_score.npz"))
+        bits = g[f"{model}/head_score"]
+        is_bf16 = bool(g[f"{model}/is_bf16"][0])
+        hs = torch.from_numpy(bits.astype(np.int16)).view(torch.bfloat16 if is_bf16 else torch.float16)
+        if tuple(hs.shape) == (L, Hkv):
+            return hs.to(dtype), "reference utils/head_score values (tests/golden/g4_head_score.npz)"
+    except (OSError, KeyError):
+        pass
+    return torch.rand(L, Hkv, generator=torch.Generator().manual_seed(7)).to(dtype), "seeded random head scores"
+
+
+def cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores):
+    """Oracle (CPU restatement of the reference path, validated bit-for-bit against the reference's golden vectors) timed on
+    this box's host cores on a bounded sample of the same workload.  The same sample doubles as a parity check of the HIP
+    scoring kernel at the headline shape (`parity_sample`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kvzip_oracle as orc
+    from kvzip_amd import ops
+    sink, N, chunk, ratio = args.sink, args.ctx, args.chunk, args.ratio
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    m, q_len = chunk, chunk + 26
-    # one scoring chunk of one layer at the full geometry; the key tensor only needs sink + chunk + q rows
-    klen = sink + m + q_len
-    q = torch.randn(1, H, q_len, D, generator=g).to(dtype)
-    k = torch.randn(1, Hkv, klen, D, generator=g).to(dtype)
-    t_lc, n_lc = 0.0, 0
-    while t_lc < 10.0 and n_lc < 4:
+    parity = None
+    if args.level == "head":
         t0 = time.perf_counter()
-        orc.get_score(q, k, sink, sink, sink + m)
-        t_lc += time.perf_counter() - t0
-        n_lc += 1
-    t_lc /= n_lc
-    # selection over all L*Hkv*N scores and compaction of ONE layer at full N
-    score = (torch.rand(L, 1, Hkv, N, generator=g) ** 8).to(dtype)
-    t0 = time.perf_counter()
-    valid, _ = orc.threshold(score, ratio)
-    t_sel = time.perf_counter() - t0
-    K1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
-    V1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
-    t0 = time.perf_counter()
-    orc.prepare_init(K1, V1, valid[:1], sink)
-    t_cmp = time.perf_counter() - t0
-    n_chunks = math.ceil(N / chunk)
-    total = n_chunks * L * t_lc + t_sel + L * t_cmp
-    return {
-        "value": N / total, "unit": "tokens/s", "cores": cores, "kind": "port",
-        "sample": (f"{n_lc} of {n_chunks * L} (layer,chunk) get_score calls at full geometry "
-                   f"({t_lc:.2f} s each), threshold over all {L * Hkv * N} scores ({t_sel:.2f} s), prepare_init of 1 of "
-                   f"{L} layers ({t_cmp:.2f} s); extrapolated to the whole context"),
-    }
+        kept, _ = orc.threshold_heads(head_scores, N, ratio)
+        valid1 = kept[:1].unsqueeze(1).unsqueeze(-1).expand(1, 1, Hkv, N).contiguous()
+        t_sel = time.perf_counter() - t0
+        K1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
+        V1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
+        t0 = time.perf_counter()
+        orc.prepare_init(K1, V1, valid1, sink)
+        t_cmp = time.perf_counter() - t0
+        total = t_sel + L * t_cmp
+        sample = (f"head-level selection over {L * Hkv} head scores ({t_sel * 1e3:.1f} ms), prepare_init of 1 of {L} layers "
+                  f"({t_cmp:.2f} s); extrapolated to the whole context")
+    else:
+        m, q_len = min(chunk, N), min(chunk, N) + 26
+        klen = sink + m + q_len   # the key tensor only needs sink + chunk + q rows
+        qf = torch.randn(1, H, q_len, D, generator=g)
+        kf = torch.randn(1, Hkv, klen, D, generator=g)
+        q, k = qf.to(dtype), kf.to(dtype)
+        t_lc, n_lc, want = 0.0, 0, None
+        while t_lc < 10.0 and n_lc < 4:
+            t0 = time.perf_counter()
+            want = orc.get_score(q, k, sink, sink, sink + m)
+            t_lc += time.perf_counter() - t0
+            n_lc += 1
+        t_lc /= n_lc
+        # ---- parity of the HIP kernels on exactly these tensors (bench dtype from the timed call, the other dtype once more)
+        parity = {}
+        for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+            qq, kk = qf.to(dt), kf.to(dt)
+            ref = want if dt == dtype else orc.get_score(qq, kk, sink, sink, sink + m)
+            got = ops.score_chunk(qq.to(dev), kk.to(dev), sink, sink, sink + m).cpu()
+            d = (ulp_keys(got) - ulp_keys(ref)).abs()
+            v_ref, _ = orc.threshold(ref.unsqueeze(0), ratio)
+            v_got, _ = orc.threshold(got.unsqueeze(0), ratio)
+            parity[name] = {"bit_identical": float((d == 0).float().mean()), "within_1ulp": float((d <= 1).float().mean()),
+                            "worst_ulp": int(d.max()), f"mask_hamming@{ratio}": float((v_ref != v_got).float().mean()),
+                            "scores": int(d.numel())}
+        parity["shape"] = f"H{H} Hkv{Hkv} D{D} m{m} q{q_len} sink{sink} (one (layer,chunk) call of the bench workload vs the CPU oracle)"
+        # selection over all L*Hkv*N scores and compaction of ONE layer at full N
+        score = (torch.rand(L, 1, Hkv, N, generator=g) ** 8).to(dtype)
+        t0 = time.perf_counter()
+        valid, _ = orc.threshold(score, ratio)
+        t_sel = time.perf_counter() - t0
+        K1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
+        V1 = [torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)]
+        t0 = time.perf_counter()
+        orc.prepare_init(K1, V1, valid[:1], sink)
+        t_cmp = time.perf_counter() - t0
+        n_chunks = math.ceil(N / chunk)
+        total = n_chunks * L * t_lc + t_sel + L * t_cmp
+        sample = (f"{n_lc} of {n_chunks * L} (layer,chunk) get_score calls at full geometry ({t_lc:.2f} s each), threshold "
+                  f"over all {L * Hkv * N} scores ({t_sel:.2f} s), prepare_init of 1 of {L} layers ({t_cmp:.2f} s); "
+                  "extrapolated to the whole context")
+    return {"value": N / total, "unit": "tokens/s", "cores": cores, "kind": "port", "sample": sample}, parity
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
+def main(argv=None):
+    args = parse(argv)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    ranks = Ranks(args.gpus, "nccl", dev)
+    rank, world = ranks.rank, ranks.world
 
     from kvzip_amd import _lib
     from kvzip_amd.kvcache import EvictCache
     lib = _lib.load()
 
     L, H, Hkv, D = GEOM[args.model]
-    G = H // Hkv
     dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
     sink, N, ratio = args.sink, args.ctx, args.ratio
+    head_level = args.level == "head"
     # scoring chunks exactly as model/wrapper.py:197-221: 2000-token chunks, repeat prompt overhead 13 / 26 tokens
     chunks = []
     for c, st in enumerate(range(0, N, args.chunk)):
@@ -146,12 +269,18 @@ def main():
     for l in range(L):
         store_k[l][:, :, :sink + N] = randn(1, Hkv, sink + N, D)
         store_v[l][:, :, :sink + N] = randn(1, Hkv, sink + N, D)
-    pool = len(chunks) if args.q_pool <= 0 else min(args.q_pool, len(chunks))
     Qs, Ks, Vs = [], [], []
-    for p in range(pool):
-        Qs.append(randn(L, 1, H, q_max, D))
-        Ks.append(randn(L, 1, Hkv, q_max, D))
-        Vs.append(randn(L, 1, Hkv, q_max, D))
+    pool = 0
+    head_scores, head_src = None, None
+    if head_level:
+        head_scores, head_src = head_scores_for(args.model, L, Hkv, dtype)
+        hs_dev = head_scores.to(dev)
+    else:
+        pool = len(chunks) if args.q_pool <= 0 else min(args.q_pool, len(chunks))
+        for p in range(pool):
+            Qs.append(randn(L, 1, H, q_max, D))
+            Ks.append(randn(L, 1, Hkv, q_max, D))
+            Vs.append(randn(L, 1, Hkv, q_max, D))
     cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
 
     period = max(1, args.prof_period)
@@ -161,64 +290,58 @@ def main():
         kv = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
         kv.n_score_streams = max(1, args.score_streams)
         kv.adopt_dense(store_k, store_v, sink + N)
-        kv.init_score()
-        for c, (st, en, q_len) in enumerate(chunks):
-            kv.start_idx, kv.end_idx = st, en          # model/wrapper.py:238-244
-            seen = kv._seen_tokens
-            Qc, Kc, Vc = Qs[c % pool], Ks[c % pool], Vs[c % pool]
-            for l in range(L):
-                k_all, _ = kv.update(Kc[l][:, :, :q_len], Vc[l][:, :, :q_len], l)  # attention/attn.py:44-48
-                # kernel timings: every `period`-th scoring call runs ALONE on the caller's stream, bracketed by hipEvents;
-                # all other calls overlap on the side streams (their kernels share the GPU, so their brackets would not
-                # measure a kernel)
-                sample = timing["on"] and timing["n"] % period == 0
-                timing["n"] += 1
-                if sample:
-                    kv._wait_score()
-                    kv._score_exclusive = True
-                    lib.kvz_prof_enable(1)
-                kv._get_score(Qc[l][:, :, :q_len], k_all, l)                        # attention/attn.py:53-54
-                if sample:
-                    lib.kvz_prof_enable(0)
-                    kv._score_exclusive = False
-            kv.slice(seen)
+        if head_level:
+            # what ModelKVzip.scoring(load_score=True) leaves behind: a stride-0 view of the [L,Hkv] head scores
+            kv.score = hs_dev.unsqueeze(-1).expand(-1, -1, N).unsqueeze(1)
+        else:
+            kv.init_score()
+            for c, (st, en, q_len) in enumerate(chunks):
+                kv.start_idx, kv.end_idx = st, en          # model/wrapper.py:238-244
+                seen = kv._seen_tokens
+                Qc, Kc, Vc = Qs[c % pool], Ks[c % pool], Vs[c % pool]
+                for l in range(L):
+                    k_all, _ = kv.update(Kc[l][:, :, :q_len], Vc[l][:, :, :q_len], l)  # attention/attn.py:44-48
+                    # kernel timings: every `period`-th scoring call runs ALONE on the caller's stream, bracketed by hipEvents;
+                    # all other calls overlap on the side streams (their kernels share the GPU, so their brackets would not
+                    # measure a kernel)
+                    sample = timing["on"] and timing["n"] % period == 0
+                    timing["n"] += 1
+                    if sample:
+                        kv._wait_score()
+                        kv._score_exclusive = True
+                        lib.kvz_prof_enable(1)
+                    kv._get_score(Qc[l][:, :, :q_len], k_all, l)                        # attention/attn.py:53-54
+                    if sample:
+                        lib.kvz_prof_enable(0)
+                        kv._score_exclusive = False
+                kv.slice(seen)
         kv.start_idx, kv.get_score = sink, False
         timing["issued"] = time.perf_counter()
         if timing["on"]:
             lib.kvz_prof_enable(1)
-        thres, r_real = kv.prune(ratio)                                               # attention/kvcache.py:123-138
+        thres, r_real = kv.prune(ratio, "head" if head_level else "pair")            # attention/kvcache.py:123-138
         lib.kvz_prof_enable(0)
         return kv, thres, r_real
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         kv, thres, r_real = one_step()
     lib.kvz_prof_reset()
     timing["on"] = True
-    barrier()
+    ranks.barrier(torch.cuda.synchronize)
     t0 = time.perf_counter()
     host_issue = 0.0
     for _ in range(args.steps):
         ts = time.perf_counter()
         kv, thres, r_real = one_step()
         host_issue += timing["issued"] - ts  # time the host needed to enqueue the scoring of one context
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the only exchange of the path (inside the timed region): the result record of every context, library gather
+    records = ranks.gather_records(thres, r_real, torch.stack(kv.info["len_k"]), L, Hkv)
+    ranks.barrier(torch.cuda.synchronize)
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0, dev)
     timing["on"] = False
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # the only exchange the path has: a fixed-size result record per context, gathered over RCCL/xGMI
-        rec = torch.tensor([thres, r_real, float(sum(kv.info["rows_used"]))], dtype=torch.float64, device=dev)
-        recs = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(recs, rec)
+    assert len(records) == world and all(r is not None and r["n_kept"] > 0 for r in records)
 
-    prof = {n: prof_read(lib, n) for n in ("score_rowstat", "score_colmax", "select", "compact_gather")}
+    prof = {n: prof_read(lib, n) for n in ("score_rowstat", "score_colmax", "select", "select_heads", "compact_gather")}
 
     # ---- post-prune decode: append + variable-length attention, q_len = 1 (attention only) ------------------
     lib.kvz_prof_reset()
@@ -247,69 +370,75 @@ def main():
     lib.kvz_prof_enable(0)
     attn_ms, attn_n = prof_read(lib, "varlen_attn")
     kept_rows = sum(kv.info["rows_used"])
+    len_k_host = kv.info["len_k_host"]
     kv.slice(seen)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        ranks.close()
         return
 
     # ---- roofline of the dominant kernel (live hipEvent timings over the timed region) -----------------------
-    flops_lc = [2.0 * H * D * q * (sink + (en - st) + q) for (st, en, q) in chunks]      # QK^T only
-    flops_b = [2.0 * H * D * q * (en - st) for (st, en, q) in chunks]                       # pass-B recompute (ctx columns)
-    avg_flops_a = sum(flops_lc) / len(chunks)
-    avg_flops_b = sum(flops_b) / len(chunks)
-
     def stage(name, work, unit_scale):
         ms, n = prof[name]
         if n == 0:
-            return None
+            return None, None, 0
         avg_s = ms / n / 1e3
         return work / avg_s / unit_scale, ms / n, n
 
-    a_tf, a_ms, a_n = stage("score_rowstat", avg_flops_a, 1e12)
-    b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
     row_bytes = D * 2
-    compact_bytes = 2.0 * 2.0 * kept_rows * row_bytes + L * Hkv * N                          # read+write kept rows of K and V + mask
+    mask_bytes = L * Hkv * (1 if head_level else N)
+    compact_bytes = 2.0 * 2.0 * kept_rows * row_bytes + mask_bytes                           # read+write kept rows of K and V + mask
     c_gbs, c_ms, c_n = stage("compact_gather", compact_bytes, 1e9)
-    select_bytes = 5.0 * L * Hkv * N
-    s_gbs, s_ms, s_n = stage("select", select_bytes, 1e9)
-    dominant = "score_rowstat" if a_ms >= b_ms else "score_colmax"
-    dom_tf = a_tf if dominant == "score_rowstat" else b_tf
-    score_combined_tf = avg_flops_a / ((a_ms + b_ms) / 1e3) / 1e12
     decode_bytes = 2.0 * (kept_rows + Hkv * L) * row_bytes                                    # every kept K and V row once per token
     attn_gbs = decode_bytes / L / (attn_ms / attn_n / 1e3) / 1e9 if attn_n else None
 
-    # HBM traffic of the bandwidth-bound kernels, measured offline with PMC counters (separate rocprofv3 --pmc passes,
-    # see profiles/r1_pmc_traffic.json); only attached when the bench runs the geometry it was measured on
+    # HBM traffic of the kernels, measured offline with PMC counters (separate rocprofv3 --pmc passes, see
+    # profiles/*_pmc_traffic.json); only attached when the bench runs the geometry it was measured on
     pmc = {}
     try:
-        if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9 and not head_level:
+            for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(path):
+                    pmc = json.load(open(path))
+                    break
     except (OSError, ValueError):
         pmc = {}
-    out = {
-        "metric": "kv_tokens_scored_and_pruned_per_s", "value": world * N * args.steps / elapsed, "unit": "tokens/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {
-            "workload": (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, "
-                         f"{len(chunks)} scoring chunks of {args.chunk}, ratio {ratio}: score + select + compact; "
-                         "one independent context per GPU"),
-            "ratio": ratio, "real_ratio": r_real, "threshold": thres, "kept_rows": int(kept_rows),
-            "parallelism": f"1 context per GPU x{world}, no data-path collective",
-            "score_streams": max(1, args.score_streams),
-            "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,
-        },
-        "roofline": {
-            "bound": "mfma", "kernel": dominant, "achieved": dom_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": pmc.get(dominant, {}).get("traffic_bytes"),
-            "note": ("algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) launch (QK^T only, SURVEY §8d); "
-                     "score_combined = same flops over rowstat+colmax time; kernel durations from hipEvents on the launch "
-                     f"stream inside the timed region: every {max(1, args.prof_period)}th scoring call runs alone on the caller's "
-                     f"stream and is bracketed, the others overlap on {max(1, args.score_streams)} side streams"),
-        },
-        "roofline_stages": {
+    stages = {
+        "compact_gather": {"bound": "hbm", "achieved": c_gbs, "unit": "GB/s", "frac": c_gbs / HBM_PEAK_GBS if c_gbs else None,
+                           "avg_ms": c_ms, "launches": c_n, "algorithmic_bytes": compact_bytes,
+                           "traffic": pmc.get("compact_gather", {}).get("traffic_bytes")},
+        "decode_varlen_attn": {"bound": "hbm", "achieved": attn_gbs, "unit": "GB/s",
+                               "frac": (attn_gbs / HBM_PEAK_GBS) if attn_gbs else None,
+                               "avg_ms": (attn_ms / attn_n) if attn_n else None, "launches": attn_n,
+                               "algorithmic_bytes": decode_bytes / L,
+                               "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes")},
+    }
+    if head_level:
+        h_ms, h_n = prof["select_heads"]
+        stages["select_heads"] = {"bound": "launch", "avg_ms": h_ms / h_n if h_n else None, "launches": h_n,
+                                  "algorithmic_bytes": 3.0 * L * Hkv}
+        roofline = {"bound": "hbm", "kernel": "compact_gather", "achieved": c_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": c_gbs / HBM_PEAK_GBS, "traffic": None,
+                    "note": ("algorithmic bytes = read + write of every kept K and V row (2*2*kept_rows*D*2 B) + one mask byte per "
+                             "(layer, head); a dropped head contributes only its sink rows; duration from hipEvents around the "
+                             "single gather launch of every timed step")}
+        workload = (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, --level head "
+                    f"(context-independent head scores: {head_src}), ratio {ratio}: head-level select + compact; post-prune "
+                    "decode reported beside it; one independent context per GPU")
+        metric = "kv_tokens_pruned_per_s"
+    else:
+        flops_lc = [2.0 * H * D * q * (sink + (en - st) + q) for (st, en, q) in chunks]      # QK^T only
+        flops_b = [2.0 * H * D * q * (en - st) for (st, en, q) in chunks]                       # pass-B recompute (ctx columns)
+        avg_flops_a = sum(flops_lc) / len(chunks)
+        avg_flops_b = sum(flops_b) / len(chunks)
+        a_tf, a_ms, a_n = stage("score_rowstat", avg_flops_a, 1e12)
+        b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
+        s_gbs, s_ms, s_n = stage("select", 5.0 * L * Hkv * N, 1e9)
+        dominant = "score_rowstat" if a_ms >= b_ms else "score_colmax"
+        dom_tf = a_tf if dominant == "score_rowstat" else b_tf
+        score_combined_tf = avg_flops_a / ((a_ms + b_ms) / 1e3) / 1e12
+        stages.update({
             "score_rowstat": {"bound": "mfma", "achieved": a_tf, "unit": "TFLOP/s", "frac": a_tf / MFMA_PEAK_TFLOPS,
                               "avg_ms": a_ms, "launches": a_n},
             "score_colmax": {"bound": "mfma", "achieved": b_tf, "unit": "TFLOP/s", "frac": b_tf / MFMA_PEAK_TFLOPS,
@@ -318,26 +447,49 @@ def main():
                                "frac": score_combined_tf / MFMA_PEAK_TFLOPS},
             "select": {"bound": "hbm", "achieved": s_gbs, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS, "avg_ms": s_ms,
                        "launches": s_n},
-            "compact_gather": {"bound": "hbm", "achieved": c_gbs, "unit": "GB/s", "frac": c_gbs / HBM_PEAK_GBS,
-                               "avg_ms": c_ms, "launches": c_n, "algorithmic_bytes": compact_bytes,
-                               "traffic": pmc.get("compact_gather", {}).get("traffic_bytes")},
-            "decode_varlen_attn": {"bound": "hbm", "achieved": attn_gbs, "unit": "GB/s",
-                                   "frac": (attn_gbs / HBM_PEAK_GBS) if attn_gbs else None,
-                                   "avg_ms": (attn_ms / attn_n) if attn_n else None, "launches": attn_n,
-                                   "algorithmic_bytes": decode_bytes / L,
-                                   "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes")},
+        })
+        roofline = {
+            "bound": "mfma", "kernel": dominant, "achieved": dom_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": pmc.get(dominant, {}).get("traffic_bytes"),
+            "note": ("algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) launch (QK^T only, SURVEY §8d); "
+                     "score_combined = same flops over rowstat+colmax time; kernel durations from hipEvents on the launch "
+                     f"stream inside the timed region: every {period}th scoring call runs alone on the caller's "
+                     f"stream and is bracketed, the others overlap on {max(1, args.score_streams)} side streams"),
+        }
+        workload = (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, "
+                    f"{len(chunks)} scoring chunks of {args.chunk}, ratio {ratio}: score + select + compact; "
+                    "one independent context per GPU")
+        metric = "kv_tokens_scored_and_pruned_per_s"
+
+    lens = [x for row in len_k_host for x in row]
+    out = {
+        "metric": metric, "value": world * N * args.steps / elapsed, "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {
+            "workload": workload, "level": args.level,
+            "ratio": ratio, "real_ratio": r_real, "threshold": thres, "kept_rows": int(kept_rows),
+            "head_len_min_max": [int(min(lens)), int(max(lens))],
+            "parallelism": f"1 context per GPU x{world}, no data-path collective; result records gathered by "
+                           "kvzip_amd.dist.gather_results inside the timed region",
+            "gathered_contexts": len(records),
+            "score_streams": max(1, args.score_streams),
+            "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,
         },
+        "roofline": roofline,
+        "roofline_stages": stages,
         "decode": {"tokens_per_s": T / t_dec, "ms_per_token": t_dec / T * 1e3, "tokens": T,
                    "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded"},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(L, H, Hkv, D, sink, N, args.chunk, dtype, ratio)
+        out["cpu_baseline"], parity = cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores)
+        if parity is not None:
+            out["parity_sample"] = parity
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
-    main()
+    launch(sys.argv[1:], main, parse(sys.argv[1:]).gpus)

@@ -118,6 +118,25 @@ int kvz_select_topk_rows(const void* scores, int64_t rows, int64_t row_len, int6
                          kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * a17  head-level selection          reference: model/wrapper.py:40-58 feeding attention/score.py:88-102
+ *
+ * The reference expands the [L, Hkv] head scores to [L, 1, Hkv, N] and runs the global threshold on L*Hkv*N values.
+ * Every head value appears N times, so  thres = head value of rank  max((int64)((double)(rows*N)*ratio) - 1, 0) / N
+ * (descending, duplicates counted)  and  valid_heads[r] = head_scores[r] > thres.  Nothing of size N is touched.
+ *   head_scores : rows = L*Hkv half values      valid_heads : rows bytes (0/1)
+ *   row_counts  : optional int32[rows] = N for a kept head, 0 otherwise
+ *   kept_dev    : int64[1] = N * number of kept heads (what the expanded mask would sum to)
+ *   ratio >= 1  -> all ones, thres = 0
+ * ------------------------------------------------------------------------- */
+int kvz_select_heads(const void* head_scores, int rows, int64_t N, double ratio, int dtype,
+                     uint8_t* valid_heads, int32_t* row_counts, float* thres_dev, int64_t* kept_dev,
+                     kvz_stream_t stream);
+
+/* f4  head-score production          reference: test.py:22-25  (torch.stack(kv.score).squeeze().amax(-1))
+ *   out[r] = max over the row_len scores of row r (16-bit patterns, compared as numbers)  */
+int kvz_rowmax16(const void* scores, int64_t rows, int64_t row_len, int dtype, void* out, kvz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * a8+a9  compaction plan + gather    reference: attention/kvcache.py:140-185
  *
  * Plan (all layers at once).  For row r = layer*Hkv + h:
@@ -153,6 +172,18 @@ int kvz_compact_layers(const void* const* k_ptrs, const void* const* v_ptrs, int
                        const uint8_t* valid, const int32_t* tile_base, const int32_t* seg_start,
                        int layers, int Hkv, int N, int sink, int klen, int D, int elem_bytes,
                        void* const* k_out_ptrs, void* const* v_out_ptrs, kvz_stream_t stream);
+
+/* Head-level variants of the plan and the batched gather (a17): `valid_heads` holds ONE byte per (layer, head); the full
+ * mask of a row is  ones(sink) ++ (valid_heads[r] ? ones(N) : zeros(N)) ++ ones(klen - sink - N),  i.e. a kept head moves
+ * all of its rows and a dropped head only its sink rows.  Same outputs and layout as kvz_compact_plan / kvz_compact_layers. */
+int kvz_compact_plan_heads(const uint8_t* valid_heads, int layers, int Hkv, int N, int sink, int klen,
+                           int slack,
+                           int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
+                           int32_t* tile_base, kvz_stream_t stream);
+int kvz_compact_layers_heads(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
+                             const uint8_t* valid_heads, const int32_t* tile_base, const int32_t* seg_start,
+                             int layers, int Hkv, int N, int sink, int klen, int D, int elem_bytes,
+                             void* const* k_out_ptrs, void* const* v_out_ptrs, kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * a11  update_flatten_view           reference: csrc/csrc/cuda_api.cu:15-111

@@ -30,10 +30,14 @@ SIGNATURES = {
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvz_select_topk_rows": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
+    "kvz_select_heads": (_i, [_vp, _i, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp]),
+    "kvz_rowmax16": (_i, [_vp, _i64, _i64, _i, _vp, _vp]),
     "kvz_compact_plan_bytes": (_sz, [_i, _i, _i]),
     "kvz_compact_plan": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kvz_compact_layer": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_compact_layers": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "kvz_compact_plan_heads": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvz_compact_layers_heads": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

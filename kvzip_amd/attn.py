@@ -29,9 +29,10 @@ def dense_causal_attention(module, query, key, value, attention_mask=None, dropo
     if q_len == k_len:
         causal = q_len > 1
     elif q_len > 1:
-        i = torch.arange(q_len, device=query.device).view(q_len, 1)
-        j = torch.arange(k_len, device=query.device).view(1, k_len)
-        mask = j <= i + (k_len - q_len)
+        # bottom-right aligned causal mask as a BIAS OBJECT, never a materialised [q, k] tensor: a dense boolean mask is
+        # 270 MB per layer call at q = 2026, k = 133 k and rules out the flash / memory-efficient backends
+        from torch.nn.attention.bias import causal_lower_right
+        mask = causal_lower_right(q_len, k_len)
     out = F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scaling,
                                          enable_gqa=G > 1)
     return out.transpose(1, 2), None

@@ -20,11 +20,13 @@ static_assert(CP_PER_THREAD == 4, "tile/threads layout");
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // full-mask value of position p in [0, klen): ones(sink) ++ valid ++ ones(rest)
-__device__ static inline uint32_t full_mask4(const uint8_t* __restrict__ vrow, int p0, int sink, int N, int klen) {
+// tok1 = 1: one mask byte per context token; tok1 = 0: ONE byte per (layer, head) row (head-level eviction,
+// reference model/wrapper.py:40-58: the whole context of a head is kept or dropped)
+__device__ static inline uint32_t full_mask4(const uint8_t* __restrict__ vrow, int p0, int sink, int N, int klen, int tok1) {
     // returns 4 mask bits (bit j = position p0+j), positions >= klen are 0
     uint32_t bits = 0;
     const int c0 = p0 - sink;
-    if (p0 >= sink && p0 + 3 < sink + N && ((reinterpret_cast<uintptr_t>(vrow + c0) & 3u) == 0)) {
+    if (tok1 && p0 >= sink && p0 + 3 < sink + N && ((reinterpret_cast<uintptr_t>(vrow + c0) & 3u) == 0)) {
         uint32_t w = *reinterpret_cast<const uint32_t*>(vrow + c0);
         bits = ((w & 0xFFu) ? 1u : 0u) | ((w & 0xFF00u) ? 2u : 0u) | ((w & 0xFF0000u) ? 4u : 0u) |
                ((w & 0xFF000000u) ? 8u : 0u);
@@ -35,7 +37,7 @@ __device__ static inline uint32_t full_mask4(const uint8_t* __restrict__ vrow, i
             uint32_t b;
             if (p >= klen) b = 0;
             else if (p < sink || p >= sink + N) b = 1;
-            else b = vrow[p - sink] ? 1u : 0u;
+            else b = vrow[tok1 ? p - sink : 0] ? 1u : 0u;
             bits |= b << j;
         }
     }
@@ -44,13 +46,13 @@ __device__ static inline uint32_t full_mask4(const uint8_t* __restrict__ vrow, i
 
 // ---- plan, step 1: kept tokens per (row, tile) ------------------------------------------------
 __global__ __launch_bounds__(CP_THREADS) void compact_tile_count_kernel(const uint8_t* __restrict__ valid, int N,
-                                                                       int sink, int klen, int ntiles,
+                                                                       int sink, int klen, int ntiles, int tok1,
                                                                        int32_t* __restrict__ tile_cnt) {
     const int tile = blockIdx.x;
     const int row = blockIdx.y;
-    const uint8_t* vrow = valid + (int64_t)row * N;
+    const uint8_t* vrow = valid + (int64_t)row * (tok1 ? N : 1);
     const int p0 = tile * CT + threadIdx.x * CP_PER_THREAD;
-    int c = __popc(full_mask4(vrow, p0, sink, N, klen));
+    int c = __popc(full_mask4(vrow, p0, sink, N, klen, tok1));
     __shared__ int ws[CP_THREADS / WAVE];
     int w = wave_reduce_sum(c);
     if (lane_id() == 0) ws[threadIdx.x >> 6] = w;
@@ -116,7 +118,8 @@ struct CompactArgs {
     const void* v_single;
     void* k_out_single;
     void* v_out_single;
-    const uint8_t* valid;        // [layers*Hkv, N]
+    const uint8_t* valid;        // [layers*Hkv, N]  (tok1 = 0: [layers*Hkv], one byte per head)
+    int tok1;
     const int32_t* tile_base;    // [layers*Hkv, ntiles]
     const int32_t* seg_start;    // [layers*Hkv]
     int64_t in_head_stride_bytes;
@@ -135,9 +138,9 @@ __global__ __launch_bounds__(CP_THREADS) void compact_gather_kernel(CompactArgs 
     __shared__ uint16_t list[CT];
     __shared__ int wtot[CP_THREADS / WAVE];
 
-    const uint8_t* vrow = a.valid + (int64_t)row * a.N;
+    const uint8_t* vrow = a.valid + (int64_t)row * (a.tok1 ? a.N : 1);
     const int p0 = tile * CT + threadIdx.x * CP_PER_THREAD;
-    const uint32_t bits = full_mask4(vrow, p0, a.sink, a.N, a.klen);
+    const uint32_t bits = full_mask4(vrow, p0, a.sink, a.N, a.klen, a.tok1);
     const int c = __popc(bits);
     const int inc = wave_inclusive_scan(c);
     if (lane_id() == 63) wtot[threadIdx.x >> 6] = inc;
@@ -264,9 +267,9 @@ extern "C" size_t kvz_compact_plan_bytes(int layers, int Hkv, int klen) {
     return (size_t)layers * Hkv * ntiles_of(klen) * sizeof(int32_t);
 }
 
-extern "C" int kvz_compact_plan(const uint8_t* valid, int layers, int Hkv, int N, int sink, int klen, int slack,
-                                int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
-                                int32_t* tile_base, kvz_stream_t stream_) {
+static int compact_plan_impl(const uint8_t* valid, int tok1, int layers, int Hkv, int N, int sink, int klen, int slack,
+                             int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
+                             int32_t* tile_base, kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(valid && len_k && cu_len_k && seg_start && max_len_k && tile_base, KVZ_EINVAL,
                 "kvz_compact_plan: null pointer");
@@ -276,12 +279,23 @@ extern "C" int kvz_compact_plan(const uint8_t* valid, int layers, int Hkv, int N
     KVZ_REQUIRE((int64_t)layers * Hkv <= 65535, KVZ_EINVAL, "kvz_compact_plan: too many rows");
     const int nt = ntiles_of(klen);
     hipLaunchKernelGGL(compact_tile_count_kernel, dim3(nt, layers * Hkv), dim3(CP_THREADS), 0, stream, valid, N, sink,
-                       klen, nt, tile_base);
+                       klen, nt, tok1, tile_base);
     KVZ_CHECK_LAUNCH("compact_tile_count_kernel");
     hipLaunchKernelGGL(compact_plan_scan_kernel, dim3(layers), dim3(CP_THREADS), 0, stream, Hkv, nt, slack, tile_base,
                        len_k, cu_len_k, seg_start, max_len_k);
     KVZ_CHECK_LAUNCH("compact_plan_scan_kernel");
     return KVZ_OK;
+}
+
+extern "C" int kvz_compact_plan(const uint8_t* valid, int layers, int Hkv, int N, int sink, int klen, int slack,
+                                int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
+                                int32_t* tile_base, kvz_stream_t stream) {
+    return compact_plan_impl(valid, 1, layers, Hkv, N, sink, klen, slack, len_k, cu_len_k, seg_start, max_len_k, tile_base, stream);
+}
+extern "C" int kvz_compact_plan_heads(const uint8_t* valid_heads, int layers, int Hkv, int N, int sink, int klen, int slack,
+                                      int32_t* len_k, int32_t* cu_len_k, int32_t* seg_start, int32_t* max_len_k,
+                                      int32_t* tile_base, kvz_stream_t stream) {
+    return compact_plan_impl(valid_heads, 0, layers, Hkv, N, sink, klen, slack, len_k, cu_len_k, seg_start, max_len_k, tile_base, stream);
 }
 
 static int check_rows(const char* who, int D, int elem_bytes, int64_t in_head_stride) {
@@ -304,17 +318,17 @@ extern "C" int kvz_compact_layer(const void* k, const void* v, int64_t in_head_s
     if (rc) return rc;
     CompactArgs a{};
     a.k_single = k; a.v_single = v; a.k_out_single = k_out; a.v_out_single = v_out;
-    a.valid = valid; a.tile_base = tile_base; a.seg_start = seg_start;
+    a.valid = valid; a.tok1 = 1; a.tile_base = tile_base; a.seg_start = seg_start;
     a.in_head_stride_bytes = in_head_stride * elem_bytes;
     a.Hkv = Hkv; a.N = N; a.sink = sink; a.klen = klen; a.ntiles = ntiles_of(klen);
     a.row_bytes = D * elem_bytes;
     return launch_gather(a, 1, (hipStream_t)stream_);
 }
 
-extern "C" int kvz_compact_layers(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
-                                  const uint8_t* valid, const int32_t* tile_base, const int32_t* seg_start, int layers,
-                                  int Hkv, int N, int sink, int klen, int D, int elem_bytes, void* const* k_out_ptrs,
-                                  void* const* v_out_ptrs, kvz_stream_t stream_) {
+static int compact_layers_impl(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
+                               const uint8_t* valid, int tok1, const int32_t* tile_base, const int32_t* seg_start, int layers,
+                               int Hkv, int N, int sink, int klen, int D, int elem_bytes, void* const* k_out_ptrs,
+                               void* const* v_out_ptrs, kvz_stream_t stream_) {
     KVZ_REQUIRE(k_ptrs && v_ptrs && valid && tile_base && seg_start && k_out_ptrs && v_out_ptrs, KVZ_EINVAL,
                 "kvz_compact_layers: null pointer");
     KVZ_REQUIRE(klen >= sink + N && Hkv > 0 && layers > 0 && layers <= 65535, KVZ_EINVAL, "kvz_compact_layers: bad shape");
@@ -322,11 +336,28 @@ extern "C" int kvz_compact_layers(const void* const* k_ptrs, const void* const* 
     if (rc) return rc;
     CompactArgs a{};
     a.k_ptrs = k_ptrs; a.v_ptrs = v_ptrs; a.k_out_ptrs = k_out_ptrs; a.v_out_ptrs = v_out_ptrs;
-    a.valid = valid; a.tile_base = tile_base; a.seg_start = seg_start;
+    a.valid = valid; a.tok1 = tok1; a.tile_base = tile_base; a.seg_start = seg_start;
     a.in_head_stride_bytes = in_head_stride * elem_bytes;
     a.Hkv = Hkv; a.N = N; a.sink = sink; a.klen = klen; a.ntiles = ntiles_of(klen);
     a.row_bytes = D * elem_bytes;
     return launch_gather(a, layers, (hipStream_t)stream_);
+}
+
+extern "C" int kvz_compact_layers(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
+                                  const uint8_t* valid, const int32_t* tile_base, const int32_t* seg_start, int layers,
+                                  int Hkv, int N, int sink, int klen, int D, int elem_bytes, void* const* k_out_ptrs,
+                                  void* const* v_out_ptrs, kvz_stream_t stream) {
+    return compact_layers_impl(k_ptrs, v_ptrs, in_head_stride, valid, 1, tile_base, seg_start, layers, Hkv, N, sink, klen, D,
+                               elem_bytes, k_out_ptrs, v_out_ptrs, stream);
+}
+// head-level eviction: `valid_heads` holds ONE byte per (layer, head); a kept head moves all of its rows, a dropped head
+// only its sink rows (and whatever follows the context) - whole-segment copies, no per-token mask is ever materialised
+extern "C" int kvz_compact_layers_heads(const void* const* k_ptrs, const void* const* v_ptrs, int64_t in_head_stride,
+                                        const uint8_t* valid_heads, const int32_t* tile_base, const int32_t* seg_start,
+                                        int layers, int Hkv, int N, int sink, int klen, int D, int elem_bytes,
+                                        void* const* k_out_ptrs, void* const* v_out_ptrs, kvz_stream_t stream) {
+    return compact_layers_impl(k_ptrs, v_ptrs, in_head_stride, valid_heads, 0, tile_base, seg_start, layers, Hkv, N, sink, klen,
+                               D, elem_bytes, k_out_ptrs, v_out_ptrs, stream);
 }
 
 extern "C" int kvz_update_flatten_view(const void* cache, const void* state, const int32_t* headlens,

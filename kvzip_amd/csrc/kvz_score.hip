@@ -25,6 +25,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 namespace kvz {
@@ -937,9 +938,17 @@ static inline float f16_bits_to_f32(uint16_t h) {
 
 // returns r with  half(x * r) == half(x / c)  for every finite 16-bit x (zero sign included), or 0 if none of the
 // neighbours of 1/c qualifies.
-static float find_exact_reciprocal(float c, int dtype) {
-    static float cache[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [dtype][{c, r, valid}]
-    if (cache[dtype][2] != 0.f && cache[dtype][0] == c) return cache[dtype][1];
+static float find_exact_reciprocal_search(float c, int dtype);
+// memoised per (dtype, D): four fixed slots, each initialised exactly once (callers may come from several host threads:
+// ctypes releases the GIL) - the 5 x 65536-case search runs at most four times per process, never on a later launch path
+static float find_exact_reciprocal(int D, int dtype) {
+    static std::once_flag once[2][2];
+    static float value[2][2];
+    const int di = (D == 128) ? 1 : 0, ti = (dtype == KVZ_BF16) ? 1 : 0;
+    std::call_once(once[ti][di], [&] { value[ti][di] = find_exact_reciprocal_search(sqrtf((float)D), dtype); });
+    return value[ti][di];
+}
+static float find_exact_reciprocal_search(float c, int dtype) {
     const float base = 1.0f / c;
     float cand[5] = {base, nextafterf(base, 1.f), nextafterf(base, 0.f), 0.f, 0.f};
     cand[3] = nextafterf(cand[1], 1.f);
@@ -961,7 +970,6 @@ static float find_exact_reciprocal(float c, int dtype) {
         }
         if (ok) found = cand[ci];
     }
-    cache[dtype][0] = c; cache[dtype][1] = found; cache[dtype][2] = 1.f;
     return found;
 }
 
@@ -1042,7 +1050,7 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
-    a.rcp = find_exact_reciprocal(a.c, dtype);
+    a.rcp = find_exact_reciprocal(D, dtype);
     if (dtype == KVZ_F16) {
         if (D == 128) return launch_score<_Float16, 128>(a, Hkv, stream);
         return launch_score<_Float16, 64>(a, Hkv, stream);
@@ -1072,7 +1080,8 @@ extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtyp
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(in_bits && out_bits && n > 0, KVZ_EINVAL, "kvz_debug_round_chain: bad arguments");
     const float c = sqrtf((float)D);
-    const float rcp = force_division ? 0.f : find_exact_reciprocal(c, dtype);
+    KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_debug_round_chain: head_dim %d unsupported", D);
+    const float rcp = force_division ? 0.f : find_exact_reciprocal(D, dtype);
     if (rcp_used) *rcp_used = rcp;
     dim3 grid((n + 255) / 256), block(256);
     const uint16_t* in = reinterpret_cast<const uint16_t*>(in_bits);

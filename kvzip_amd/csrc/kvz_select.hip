@@ -344,6 +344,77 @@ __global__ __launch_bounds__(TOPK_THREADS) void select_topk_rows_kernel(const ui
     if (t == 0 && row_counts) row_counts[row] = (int32_t)k;
 }
 
+// ---- head-level selection: one score per (layer, KV head), expanded over N context tokens by the reference ---------
+// (model/wrapper.py:40-58 expands [L,Hkv] to [L,1,Hkv,N] and sorts L*Hkv*N values; every head value appears N times,
+// so the order statistic of rank idx in the expanded tensor is the head value of rank idx / N.)  One block does the whole
+// selection for up to 65536 values: 11+5-bit LDS histograms, pick, emit.
+__global__ __launch_bounds__(TOPK_THREADS) void select_small_kernel(const uint16_t* __restrict__ scores, int n, uint32_t rank,
+                                                                   int dtype, int64_t weight, uint8_t* __restrict__ valid_out,
+                                                                   int32_t* __restrict__ row_counts, float* __restrict__ thres_dev,
+                                                                   unsigned long long* __restrict__ kept_dev) {
+    __shared__ uint32_t hh[HI_BINS];
+    __shared__ uint32_t hl[LO_BINS];
+    __shared__ uint32_t s_kept;
+    const int t = threadIdx.x;
+    for (int i = t; i < HI_BINS; i += TOPK_THREADS) hh[i] = 0;
+    if (t < LO_BINS) hl[t] = 0;
+    if (t == 0) s_kept = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += TOPK_THREADS) atomicAdd(&hh[order_key16(scores[i]) >> 5], 1u);
+    __syncthreads();
+    uint32_t bin, r1, above;
+    find_bin_desc_1024<HI_BINS>(hh, rank, &bin, &r1, &above);
+    for (int i = t; i < n; i += TOPK_THREADS) {
+        const uint32_t key = order_key16(scores[i]);
+        if ((key >> 5) == bin) atomicAdd(&hl[key & 31u], 1u);
+    }
+    __syncthreads();
+    uint32_t lo, r2, above2;
+    find_bin_desc_1024<LO_BINS>(hl, r1, &lo, &r2, &above2);
+    const float thres = half_bits_to_float(order_key16_inv((bin << 5) | lo), dtype);
+    uint32_t cnt = 0;
+    for (int i = t; i < n; i += TOPK_THREADS) {
+        const uint32_t keep = half_bits_to_float(scores[i], dtype) > thres ? 1u : 0u;  // float compare: strict >, -0 == +0
+        valid_out[i] = (uint8_t)keep;
+        if (row_counts) row_counts[i] = keep ? (int32_t)weight : 0;
+        cnt += keep;
+    }
+    cnt = (uint32_t)wave_reduce_sum((int)cnt);
+    if ((t & 63) == 0 && cnt) atomicAdd(&s_kept, cnt);
+    __syncthreads();
+    if (t == 0) {
+        *thres_dev = thres;
+        *kept_dev = (unsigned long long)s_kept * (unsigned long long)weight;
+    }
+}
+
+// ---- per-row maximum of 16-bit scores (head-score production, reference test.py:22-25) ----------------------------
+__global__ __launch_bounds__(SEL_THREADS) void rowmax16_kernel(const uint16_t* __restrict__ scores, int64_t row_len, int dtype,
+                                                              uint16_t* __restrict__ out) {
+    const uint16_t* srow = scores + (int64_t)blockIdx.x * row_len;
+    float best = -INFINITY;
+    uint32_t bits = 0xFC00u;  // -inf (fp16); rewritten below for bf16
+    if (dtype == KVZ_BF16) bits = 0xFF80u;
+    for (int64_t i = threadIdx.x; i < row_len; i += SEL_THREADS) {
+        const uint32_t b = srow[i];
+        const float f = half_bits_to_float(b, dtype);
+        if (f > best || (f != f)) { best = f; bits = b; }  // a NaN wins, as in torch.amax
+    }
+    __shared__ float sb[SEL_THREADS];
+    __shared__ uint32_t sbits[SEL_THREADS];
+    sb[threadIdx.x] = best;
+    sbits[threadIdx.x] = bits;
+    __syncthreads();
+    for (int o = SEL_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float f = sb[threadIdx.x + o];
+            if (f > sb[threadIdx.x] || (f != f)) { sb[threadIdx.x] = f; sbits[threadIdx.x] = sbits[threadIdx.x + o]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint16_t)sbits[0];
+}
+
 __global__ void fill_rows_kernel(uint8_t* valid, int64_t total, uint8_t value, int32_t* row_counts, int64_t rows,
                                  int32_t count) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,5 +515,40 @@ extern "C" int kvz_select_topk_rows(const void* scores, int64_t rows, int64_t ro
     hipLaunchKernelGGL(select_topk_rows_kernel, dim3((unsigned)rows), dim3(TOPK_THREADS), 0, stream,
                        reinterpret_cast<const uint16_t*>(scores), row_len, (uint32_t)k, valid_out, row_counts);
     KVZ_CHECK_LAUNCH("select_topk_rows_kernel");
+    return KVZ_OK;
+}
+
+extern "C" int kvz_select_heads(const void* head_scores, int rows, int64_t N, double ratio, int dtype, uint8_t* valid_heads,
+                                int32_t* row_counts, float* thres_dev, int64_t* kept_dev, kvz_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(head_scores && valid_heads && thres_dev && kept_dev, KVZ_EINVAL, "kvz_select_heads: null pointer");
+    KVZ_REQUIRE(rows > 0 && rows <= 65536 && N > 0, KVZ_EINVAL, "kvz_select_heads: bad shape rows=%d N=%lld", rows, (long long)N);
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_select_heads: bad dtype %d", dtype);
+    if (!(ratio < 1.0)) {  // reference: all ones, thres = 0.
+        (void)hipMemsetAsync(valid_heads, 1, (size_t)rows, stream);
+        hipLaunchKernelGGL(select_all_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, (int64_t)rows, N, row_counts,
+                           thres_dev, reinterpret_cast<unsigned long long*>(kept_dev));
+        KVZ_CHECK_LAUNCH("select_all_kernel");
+        return KVZ_OK;
+    }
+    // idx = max(int(rows*N*ratio) - 1, 0) in the EXPANDED tensor (score.py:92-94); its head rank is idx / N
+    const double prod = (double)((int64_t)rows * N) * ratio;
+    int64_t idx = (int64_t)prod - 1;
+    if (idx < 0) idx = 0;
+    const uint32_t rank = (uint32_t)(idx / N);
+    ProfScope ps("select_heads", stream);
+    hipLaunchKernelGGL(select_small_kernel, dim3(1), dim3(TOPK_THREADS), 0, stream, reinterpret_cast<const uint16_t*>(head_scores),
+                       rows, rank, dtype, N, valid_heads, row_counts, thres_dev, reinterpret_cast<unsigned long long*>(kept_dev));
+    KVZ_CHECK_LAUNCH("select_small_kernel");
+    return KVZ_OK;
+}
+
+extern "C" int kvz_rowmax16(const void* scores, int64_t rows, int64_t row_len, int dtype, void* out, kvz_stream_t stream_) {
+    KVZ_REQUIRE(scores && out, KVZ_EINVAL, "kvz_rowmax16: null pointer");
+    KVZ_REQUIRE(rows > 0 && rows <= 0x7fffffffll && row_len > 0, KVZ_EINVAL, "kvz_rowmax16: bad shape");
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_rowmax16: bad dtype %d", dtype);
+    hipLaunchKernelGGL(rowmax16_kernel, dim3((unsigned)rows), dim3(SEL_THREADS), 0, (hipStream_t)stream_,
+                       reinterpret_cast<const uint16_t*>(scores), row_len, dtype, reinterpret_cast<uint16_t*>(out));
+    KVZ_CHECK_LAUNCH("rowmax16_kernel");
     return KVZ_OK;
 }

@@ -111,6 +111,7 @@ class _CacheBase(KVScore):
     def adopt_dense(self, store_k: List[torch.Tensor], store_v: List[torch.Tensor], filled: int):
         """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
         serving engine prefilled elsewhere); ``filled`` rows are in use."""
+        self._wait_score()  # scoring calls still in flight read the storage that is being replaced
         self._store_k, self._store_v = list(store_k), list(store_v)
         self._fill = [filled for _ in store_k]
         self.key_cache = [k[:, :, :filled] for k in self._store_k]
@@ -122,6 +123,14 @@ class _CacheBase(KVScore):
             self._fill[l] = seen_token_prev
             self.key_cache[l] = self._store_k[l][:, :, :seen_token_prev]
             self.value_cache[l] = self._store_v[l][:, :, :seen_token_prev]
+
+    def __del__(self):
+        # asynchronous scoring reads the cache storage, the score buffer and the workspaces from side streams: order the
+        # current stream behind it before the caching allocator may hand that memory to somebody else
+        try:
+            self._wait_score()
+        except Exception:
+            pass
 
     # reference: kvcache.py:108-112
     def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
@@ -425,7 +434,11 @@ class RetainCache(_CacheBase):
 
         plan = ops.compact_plan(self.valid[layer_idx:layer_idx + 1], self.sink, klen, slack=0)
         total = int(plan.cu_len_k[0, -1])  # host sync, as the reference's boolean indexing
-        k_flat, v_flat = ops.compact_layer(key_states, value_states, plan, 0, total)
+        if plan.heads:  # head-level mask (one byte per head): the batched entry point takes it
+            ks, vs = ops.compact_layers([key_states], [value_states], plan, [total])
+            k_flat, v_flat = ks[0], vs[0]
+        else:
+            k_flat, v_flat = ops.compact_layer(key_states, value_states, plan, 0, total)
         info = {
             "cu_len_q": cu_seqlens_q,
             "cu_len_k": plan.cu_len_k[0],

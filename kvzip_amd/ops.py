@@ -26,9 +26,25 @@ def _dtype_code(dtype: torch.dtype) -> int:
 
 
 def _stream(t: torch.Tensor) -> int:
+    """HIP stream handle for a launch on ``t``'s device.  The library launches on the CURRENT HIP device, so a tensor that
+    lives on another GPU (``device_map="auto"``, a cache on cuda:1 while cuda:0 is current) first makes its device current;
+    every cache object and every call of this module works on ONE device (all tensors of a call must share it)."""
     if not t.is_cuda:
         raise KvzError("the HIP path needs device tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        torch.cuda.set_device(t.device)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _same_device(*tensors) -> None:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise KvzError(f"all tensors of a call must live on one device (got {dev} and {t.device})")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -61,6 +77,7 @@ def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int,
     assert query_states.stride(-1) == 1 and query_states.stride(-2) == D
     assert key_states.stride(-1) == 1 and key_states.stride(-2) == D
     assert stream is None or (out is not None and workspace is not None)
+    _same_device(query_states, key_states, out, workspace)
     if out is None:
         out = torch.empty((1, Hkv, m), dtype=query_states.dtype, device=query_states.device)
     assert out.stride(-1) == 1 and out.shape[-1] == m
@@ -104,6 +121,37 @@ def select_threshold(score: torch.Tensor, ratio: float, row_len: Optional[int] =
     return valid, thres, kept, rows
 
 
+def select_heads(head_scores: torch.Tensor, N: int, ratio: float
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Head-level selection (reference model/wrapper.py:40-58 + attention/score.py:88-102) on the ``[L, Hkv]`` head scores
+    themselves: the threshold of the N-fold expanded tensor is the head value of rank ``idx // N``.
+    Returns ``(valid_heads bool [L, Hkv], thres f32[1], kept i64[1] (= N * kept heads), row_counts i32[L*Hkv])``."""
+    lib = _lib.load()
+    hs = head_scores.contiguous()
+    rows = hs.numel()
+    dev = hs.device
+    valid = torch.empty(hs.shape, dtype=torch.bool, device=dev)
+    thres = torch.empty(1, dtype=torch.float32, device=dev)
+    kept = torch.empty(1, dtype=torch.int64, device=dev)
+    counts = torch.empty(rows, dtype=torch.int32, device=dev)
+    rc = lib.kvz_select_heads(hs.data_ptr(), rows, int(N), float(ratio), _dtype_code(hs.dtype), valid.data_ptr(),
+                              counts.data_ptr(), thres.data_ptr(), kept.data_ptr(), _stream(hs))
+    check(rc, "kvz_select_heads")
+    return valid, thres, kept, counts
+
+
+def rowmax(score: torch.Tensor) -> torch.Tensor:
+    """Maximum over the last dim of 16-bit scores (head-score production, reference test.py:22-25)."""
+    lib = _lib.load()
+    score = score.contiguous()
+    row_len = score.shape[-1]
+    rows = score.numel() // row_len
+    out = torch.empty(score.shape[:-1], dtype=score.dtype, device=score.device)
+    rc = lib.kvz_rowmax16(score.data_ptr(), rows, row_len, _dtype_code(score.dtype), out.data_ptr(), _stream(score))
+    check(rc, "kvz_rowmax16")
+    return out
+
+
 def select_topk_rows(score: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Per-row exact top-k over the last dim (reference attention/score.py:104-120)."""
     lib = _lib.load()
@@ -139,18 +187,27 @@ class CompactPlan:
         self.tile_base = torch.empty(layers * Hkv * self.ntiles, **i32)
 
 
+def is_head_level(valid: torch.Tensor) -> bool:
+    """True for a head-level mask: one value per (layer, head) broadcast over the context (stride 0 on the last dim)."""
+    return valid.dim() >= 2 and valid.shape[-1] > 1 and valid.stride(-1) == 0
+
+
 def compact_plan(valid: torch.Tensor, sink: int, klen: int, slack: int = 0) -> CompactPlan:
-    """valid ``[L, 1, Hkv, N]`` (or ``[L, Hkv, N]``) bool -> per-layer varlen metadata on the device."""
+    """valid ``[L, 1, Hkv, N]`` (or ``[L, Hkv, N]``) bool -> per-layer varlen metadata on the device.
+    A head-level mask (``[L, 1, Hkv, 1]`` expanded over N, stride 0) is planned from its L*Hkv bytes."""
     lib = _lib.load()
-    valid = valid.contiguous()
     L = valid.shape[0]
     Hkv, N = valid.shape[-2], valid.shape[-1]
+    heads = is_head_level(valid)
+    valid = valid[..., :1].contiguous() if heads else valid.contiguous()
     plan = CompactPlan(L, Hkv, N, sink, klen, slack, valid.device)
-    rc = lib.kvz_compact_plan(valid.data_ptr(), L, Hkv, N, sink, klen, slack, plan.len_k.data_ptr(),
-                              plan.cu_len_k.data_ptr(), plan.seg_start.data_ptr(), plan.max_len_k.data_ptr(),
-                              plan.tile_base.data_ptr(), _stream(valid))
-    check(rc, "kvz_compact_plan")
+    fn = lib.kvz_compact_plan_heads if heads else lib.kvz_compact_plan
+    rc = fn(valid.data_ptr(), L, Hkv, N, sink, klen, slack, plan.len_k.data_ptr(),
+            plan.cu_len_k.data_ptr(), plan.seg_start.data_ptr(), plan.max_len_k.data_ptr(),
+            plan.tile_base.data_ptr(), _stream(valid))
+    check(rc, "kvz_compact_plan_heads" if heads else "kvz_compact_plan")
     plan.valid = valid
+    plan.heads = heads
     return plan
 
 
@@ -165,6 +222,7 @@ def compact_layer(k: torch.Tensor, v: torch.Tensor, plan: CompactPlan, layer: in
     v_out = torch.empty((total_rows, D), dtype=v.dtype, device=v.device)
     if total_rows == 0:
         return k_out, v_out
+    assert not getattr(plan, "heads", False), "head-level plans go through compact_layers"
     valid_l = plan.valid.view(plan.layers, Hkv, plan.N)[layer]
     tb = plan.tile_base.view(plan.layers, Hkv * plan.ntiles)[layer]
     rc = lib.kvz_compact_layer(k.data_ptr(), v.data_ptr(), k.stride(1), valid_l.data_ptr(), tb.data_ptr(),
@@ -192,10 +250,11 @@ def compact_layers(ks: Sequence[torch.Tensor], vs: Sequence[torch.Tensor], plan:
     table = torch.tensor([[t.data_ptr() for t in ks], [t.data_ptr() for t in vs],
                           [t.data_ptr() for t in k_outs], [t.data_ptr() for t in v_outs]],
                          dtype=torch.int64).to(dev, non_blocking=False)
-    rc = lib.kvz_compact_layers(table[0].data_ptr(), table[1].data_ptr(), hs, plan.valid.data_ptr(),
-                                plan.tile_base.data_ptr(), plan.seg_start.data_ptr(), L, Hkv, plan.N, plan.sink,
-                                klen, D, ks[0].element_size(), table[2].data_ptr(), table[3].data_ptr(),
-                                _stream(ks[0]))
+    fn = lib.kvz_compact_layers_heads if getattr(plan, "heads", False) else lib.kvz_compact_layers
+    rc = fn(table[0].data_ptr(), table[1].data_ptr(), hs, plan.valid.data_ptr(),
+            plan.tile_base.data_ptr(), plan.seg_start.data_ptr(), L, Hkv, plan.N, plan.sink,
+            klen, D, ks[0].element_size(), table[2].data_ptr(), table[3].data_ptr(),
+            _stream(ks[0]))
     check(rc, "kvz_compact_layers")
     # keep the pointer table alive until the kernel has consumed it
     table.record_stream(torch.cuda.current_stream(dev))

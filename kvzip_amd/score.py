@@ -212,12 +212,18 @@ class KVScore:
         layers x heads x tokens; strict ``>`` (ties at the threshold are evicted)."""
         score = self._stacked_score(score)
         valid, thres, kept, rows = self._threshold_device(score, ratio)
-        return valid, thres.item() if ratio < 1 else 0.
+        return valid.view(score.shape), thres.item() if ratio < 1 else 0.
 
     def _threshold_device(self, score: torch.Tensor, ratio: float):
         """Device-side part of ``_threshold`` (no host sync): valid, thres[1], kept[1], row_counts[L*Hkv]."""
-        if score.stride(-1) == 0 or not score.is_contiguous():
-            score = score.contiguous()  # e.g. head-level scores expanded over the context (model/wrapper.py:56)
+        if score.shape[-1] > 1 and score.stride(-1) == 0:
+            # head-level scores expanded over the context (model/wrapper.py:56): select on the [L, Hkv] values themselves;
+            # the mask comes back as the same kind of stride-0 view (nothing of size N is read or written)
+            N = score.shape[-1]
+            valid_h, thres, kept, rows = ops.select_heads(score[..., 0], N, ratio)
+            return valid_h.unsqueeze(-1).expand(score.shape), thres, kept, rows
+        if not score.is_contiguous():
+            score = score.contiguous()
         return ops.select_threshold(score, ratio, row_len=score.shape[-1])
 
     # reference: attention/score.py:104-120

@@ -36,12 +36,19 @@ def chunk_fn(ctx_ids: torch.Tensor, chunk_size: int) -> List[torch.Tensor]:
     return [ctx_ids[:, s:s + chunk_size] for s in range(0, n, chunk_size)]
 
 
-def load_head_score(model_name: str, ctx_len: int, head_score_dir: str, device) -> torch.Tensor:
-    """Head-level scores expanded over the context: ``[L, 1, Hkv, ctx_len]`` (reference model/wrapper.py:40-58)."""
-    name = model_name
+def head_score_name(model_name: str) -> str:
+    """File-name stem of a model's head-score files (reference model/wrapper.py:41-46)."""
     for prefix, short in (("Qwen2.5-7B", "qwen2.5-7b"), ("Qwen2.5-14B", "qwen2.5-14b"), ("Llama-3.1-8B", "llama3.1-8b")):
         if model_name.startswith(prefix):
-            name = short
+            return short
+    return model_name
+
+
+def load_head_score(model_name: str, ctx_len: int, head_score_dir: str, device) -> torch.Tensor:
+    """Head-level scores expanded over the context: ``[L, 1, Hkv, ctx_len]`` (reference model/wrapper.py:40-58).
+    The expansion is a stride-0 VIEW of the ``[L, Hkv]`` maxima: ``prune`` recognises it and selects / compacts whole
+    heads without ever materialising anything of size ``ctx_len``."""
+    name = head_score_name(model_name)
     paths = sorted(glob.glob(os.path.join(head_score_dir, f"{name}-*.pt")))
     if not paths:
         raise FileNotFoundError(f"no head-score file {name}-*.pt under {head_score_dir}")
@@ -205,7 +212,9 @@ class ModelKVzip:
             if self.eos_token_ids and int(nxt) in self.eos_token_ids:
                 break
             cur = nxt
-        a_ids = torch.cat(out_ids, dim=1)
+        # the reference drops the last generated token (model/wrapper.py:277: output[:, len(input_ids):-1]): it is the
+        # terminating EOS (or the token that hit max_new_tokens) and its KV was never written to the cache
+        a_ids = torch.cat(out_ids, dim=1)[:, :-1]
         if not update_cache:
             kv.slice(seen_token_prev)
         elif kv.prefill_ids is not None:
@@ -214,9 +223,31 @@ class ModelKVzip:
 
     def head_score(self, kv) -> torch.Tensor:
         """Per-(layer, KV head) maximum score ``[L, Hkv]`` — what the reference saves with ``--save_head_score``
-        (test.py:22-25) for context-independent, head-level eviction."""
+        (test.py:22-25: ``torch.stack(kv.score, dim=0).squeeze().amax(-1)``) for context-independent, head-level eviction."""
+        from . import ops
         score = kv._stacked_score(kv.score)
-        return score.reshape(score.shape[0], score.shape[-2], score.shape[-1]).amax(-1)
+        return ops.rowmax(score.reshape(score.shape[0], score.shape[-2], score.shape[-1]))
+
+    def save_head_score(self, kv, data: str, idx: int, head_score_dir: Optional[str] = None) -> str:
+        """Write the head scores of ``kv`` where ``load_score=True`` looks for them: ``<dir>/<name>-<data>-<idx>.pt`` holding
+        a ``[L, Hkv]`` tensor in the model dtype (reference test.py:22-25).  Several files of one model are combined by
+        ``load_head_score`` with an element-wise maximum."""
+        d = head_score_dir or self.head_score_dir
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"{head_score_name(self.name)}-{data}-{idx}.pt")
+        torch.save(self.head_score(kv).cpu(), path)
+        return path
+
+    def eval_ratios(self, kv, ratios, fn, level: str = "pair"):
+        """Multi-ratio evaluation from ONE prefill (reference eval.py:30-36): for every ratio ``kv.prune(ratio, level)`` on a
+        non-evicting cache (``kv_type="retain"``: the mask is re-applied at every attention call) and ``fn(kv)``.
+        Returns ``[([ratio, round(real_ratio, 4), round(thres, 4)], fn(kv)), ...]`` — the record layout of eval.py:34."""
+        assert isinstance(kv, RetainCache), "several ratios from one prefill need the non-evicting cache (kv_type='retain')"
+        out = []
+        for ratio in ratios:
+            thres, ratio_true = kv.prune(ratio, level)
+            out.append(([ratio, round(ratio_true, 4), round(thres, 4)], fn(kv)))
+        return out
 
     @torch.inference_mode()
     def _prob(self, input_ids: torch.Tensor, kv=None, device: str = "cuda") -> torch.Tensor:

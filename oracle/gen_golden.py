@@ -288,6 +288,30 @@ def gen_attn():
     print("g7 attn ok")
 
 
+def gen_templates():
+    """G8: outputs of the reference's template(model_name, task) (model/template.py:5-33) for the families on the path -
+    the strings decide sink = len(sys_prompt_ids) and the prompts once a real tokenizer is used."""
+    import contextlib
+    import io
+    import json
+    import importlib.util
+    # (the file is imported on its own: the reference's `model` package pulls in the HF model wrappers)
+    spec = importlib.util.spec_from_file_location("ref_template", os.path.join(REF, "model", "template.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    template = mod.template
+    out = {}
+    names = ["Llama-3.1-8B-Instruct", "duo", "Qwen2.5-7B-Instruct-1M", "Qwen2.5-14B-Instruct-1M", "Qwen3-8B",
+             "gemma3-12b", "gemma-3-4b-it", "LlamaForCausalLM", "Qwen2ForCausalLM", "mistral-7b"]
+    with contextlib.redirect_stdout(io.StringIO()):  # the fallback branch prints a warning
+        for n in names:
+            for task in ("qa", "gsm8k", "squad"):
+                out[f"{n}|{task}"] = list(template(n, task))
+    with open(os.path.join(OUT, "g8_templates.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("g8 templates ok")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -299,6 +323,7 @@ def main():
     gen_head_scores(KVScore)
     gen_cache_sequence(EvictCache, RetainCache)
     gen_attn()
+    gen_templates()
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print(f"wrote {OUT}: {total / 1e6:.2f} MB")
 

@@ -106,6 +106,20 @@ def threshold(score: Union[torch.Tensor, List[torch.Tensor]], ratio: float) -> T
 # ------------------------------------------------------------------------------------------------
 # a5  KVScore._threshold_uniform                           reference: attention/score.py:104-120
 # ------------------------------------------------------------------------------------------------
+def threshold_heads(head_scores: torch.Tensor, n_ctx: int, ratio: float) -> Tuple[torch.Tensor, float]:
+    """Head-level selection WITHOUT the expansion: the reference feeds ``head_scores[L,Hkv]`` expanded to ``[L,1,Hkv,n_ctx]``
+    to ``threshold`` (model/wrapper.py:54-57 -> attention/score.py:88-102).  In the sorted expanded tensor every head value
+    occupies ``n_ctx`` consecutive slots, hence ``sorted[idx] == sorted_heads[idx // n_ctx]``.
+    Returns ``(kept heads bool [L,Hkv], thres)``; pinned against tests/golden/g4_head_score.npz."""
+    if ratio < 1:
+        flat = head_scores.reshape(-1)
+        sorted_heads = torch.sort(flat, descending=True).values
+        n = max(int(flat.numel() * n_ctx * ratio) - 1, 0)
+        thres = sorted_heads[n // n_ctx].item()
+        return head_scores > thres, thres
+    return torch.ones_like(head_scores, dtype=torch.bool), 0.
+
+
 def threshold_uniform(scores: Union[torch.Tensor, Sequence[torch.Tensor]], ratio: float
                       ) -> Tuple[torch.Tensor, int]:
     """Per (layer, head) row keep exactly k = int(N*ratio).  torch.topk's choice among tied values is

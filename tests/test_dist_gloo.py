@@ -57,3 +57,50 @@ def test_gather_results_world2_gloo(n_ctx):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(ok and n == n_ctx for _, ok, n in res)
+
+
+# ---- bench.py's own rank logic (Ranks + launch) on gloo, world_size 2 ---------------------------------------------
+def _bench_entry(argv):
+    """What bench.main does around the kernels: Ranks from the environment, barrier, timed region, the library gather of the
+    per-context record inside it, max over ranks - with CPU tensors and the gloo backend."""
+    import json
+    import time
+    import bench
+    out_dir, L, Hkv = argv[0], int(argv[1]), int(argv[2])
+    ranks = bench.Ranks(2, "gloo")
+    ranks.barrier()
+    t0 = time.perf_counter()
+    len_k = torch.full((L, Hkv), 1000 * (ranks.rank + 1), dtype=torch.int32)
+    recs = ranks.gather_records(0.25 + ranks.rank, 0.3 + 0.01 * ranks.rank, len_k, L, Hkv)
+    ranks.barrier()
+    mine = time.perf_counter() - t0 + (0.5 if ranks.rank == 1 else 0.0)   # rank 1 pretends to be slower
+    elapsed = ranks.max_over_ranks(mine)
+    with open(os.path.join(out_dir, f"rank{ranks.rank}.json"), "w") as f:
+        json.dump({"rank": ranks.rank, "world": ranks.world, "local_rank": ranks.local_rank, "elapsed": elapsed, "mine": mine,
+                   "thres": [r["thres"] for r in recs], "n_kept": [r["n_kept"] for r in recs],
+                   "len00": [int(r["len_k"][0, 0]) for r in recs]}, f)
+    ranks.close()
+
+
+def test_bench_self_spawn_and_rank_logic_world2_gloo(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` without a launcher: bench.launch spawns the ranks itself; every rank sees the full gather
+    (kvzip_amd.dist.gather_results) and the max-over-ranks time."""
+    import json
+    import bench
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(var, raising=False)
+    bench.launch([str(tmp_path), "3", "2"], _bench_entry, 2)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, d in enumerate(res):
+        assert d["rank"] == r == d["local_rank"] and d["world"] == 2
+        assert d["thres"] == [0.25, 1.25] and d["len00"] == [1000, 2000] and d["n_kept"] == [6000, 12000]
+    assert res[0]["elapsed"] == res[1]["elapsed"] >= res[1]["mine"] >= 0.5   # MAX over ranks, identical everywhere
+
+
+def test_bench_ranks_rejects_wrong_world(monkeypatch):
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit):
+        bench.Ranks(2, "gloo")
+    args = bench.parse(["--level", "head"])
+    assert args.ratio == 0.6 and bench.parse([]).ratio == 0.3

@@ -15,6 +15,10 @@ def tiny_model(dtype=torch.float16, family="llama"):
         from transformers import LlamaConfig, LlamaForCausalLM as M
         cfg = LlamaConfig(vocab_size=160, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                           num_attention_heads=4, num_key_value_heads=2, head_dim=64, max_position_embeddings=4096)
+    elif family == "qwen3":
+        from transformers import Qwen3Config, Qwen3ForCausalLM as M
+        cfg = Qwen3Config(vocab_size=160, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, head_dim=64, max_position_embeddings=4096)
     else:
         from transformers import Qwen2Config, Qwen2ForCausalLM as M
         cfg = Qwen2Config(vocab_size=160, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
@@ -41,7 +45,7 @@ def prefill_and_score(m, ctx, rep):
     return kv
 
 
-@pytest.mark.parametrize("family", ["llama", "qwen2"])
+@pytest.mark.parametrize("family", ["llama", "qwen2", "qwen3"])
 def test_prefill_scoring_matches_oracle(family):
     m, ctx, rep, _ = make(family=family)
     kv = m.prefill(ctx, prefill_chunk_size=128, do_score=False)
@@ -113,6 +117,77 @@ def test_multi_turn_update_cache():
     q_ids = m.apply_template(query)
     seen = kv.get_seq_length()
     a = m.generate(q_ids, kv=kv, update_cache=True, return_ids=True)
-    assert kv.get_seq_length() == seen + q_ids.shape[1] + a.shape[1] - 1 or kv.get_seq_length() == seen + q_ids.shape[1] + a.shape[1]
+    # the last generated token is dropped from the answer exactly because its KV never entered the cache
+    # (reference model/wrapper.py:277): ids kept == tokens in the cache
+    assert a.shape[1] == 5
+    assert kv.get_seq_length() == seen + q_ids.shape[1] + a.shape[1]
+    assert kv.prefill_ids.shape[1] == 5 + 300 + q_ids.shape[1] + a.shape[1]
     b = m.generate(q_ids, kv=kv, return_ids=True)  # second turn sees the first
-    assert b.shape[1] >= 1
+    assert b.shape[1] == 5 and kv.get_seq_length() == seen + q_ids.shape[1] + a.shape[1]
+
+
+def test_save_head_score_and_head_level_prefill(tmp_path):
+    """f4 + a17 end to end: score a context, save its head scores in the reference's file layout (test.py:22-25), prefill a new
+    cache with load_score=True (model/wrapper.py:247) and prune at head level: whole heads are kept / dropped, generation runs."""
+    m, ctx, rep, query = make()
+    kv = prefill_and_score(m, ctx, rep)
+    hs = m.head_score(kv)
+    want = torch.stack([s for s in kv.score], dim=0).squeeze().amax(-1)
+    assert hs.shape == (2, 2) and torch.equal(hs, want)
+    m.head_score_dir = str(tmp_path)
+    path = m.save_head_score(kv, "squad", 0)
+    assert path.endswith("tiny-llama-squad-0.pt") and torch.equal(torch.load(path), want.cpu())
+    kv2 = m.prefill(ctx, prefill_chunk_size=128, load_score=True)
+    assert kv2.score.shape == (2, 1, 2, 300) and kv2.score.stride(-1) == 0 and kv2.get_score is False
+    thres, r = kv2.prune(0.5, "head")
+    kept, t_ref = orc.threshold_heads(want.cpu(), 300, 0.5)
+    assert thres == t_ref and torch.equal(kv2.valid[:, 0, :, 0].cpu(), kept) and kv2.valid.stride(-1) == 0
+    for l in range(2):
+        assert kv2.info["len_k_host"][l] == [5 + (300 if kept[l, h] else 0) for h in range(2)]
+    ids = m.generate(m.apply_template(query), kv=kv2, return_ids=True)
+    assert ids.shape == (1, 5)
+
+
+def test_eval_ratios_retain_cache():
+    """f4: several ratios from ONE prefill on the non-evicting cache (reference eval.py:30-36); every ratio gives the same
+    generation as a freshly pruned EvictCache at that ratio."""
+    m, ctx, rep, query = make("retain")
+    kr = prefill_and_score(m, ctx, rep)
+    q_ids = m.apply_template(query)
+    res = m.eval_ratios(kr, [0.9, 0.5, 0.2], lambda kv: m.generate(q_ids, kv=kv, return_ids=True))
+    assert [r[0][0] for r in res] == [0.9, 0.5, 0.2]
+    m2, _, _, _ = make("evict")
+    for (ratio, ratio_true, thres), ids in res:
+        ke = prefill_and_score(m2, ctx, rep)
+        t, r = ke.prune(ratio)
+        assert round(t, 4) == thres and round(r, 4) == ratio_true
+        assert torch.equal(m2.generate(q_ids, kv=ke, return_ids=True), ids)
+    with pytest.raises(AssertionError):
+        m2.eval_ratios(ke, [0.5], lambda kv: None)
+
+
+class _ByteTokenizer:
+    """Tokenizer stand-in (there is no network for a real one): bytes modulo the vocabulary."""
+    def encode(self, text, add_special_tokens=False, return_tensors="pt"):
+        return torch.tensor([[b % 160 for b in text.encode()]], dtype=torch.long)
+
+    def decode(self, ids):
+        return " ".join(str(int(t)) for t in ids)
+
+
+def test_model_name_constructor_path(tmp_path):
+    """ModelKVzip(<path>) (reference model/load.py:58-64 + model/wrapper.py:63-79): the model is loaded by name, the attention is
+    patched, the chat template of the family sets the sink, text goes in and out."""
+    from kvzip_amd.wrapper import ModelKVzip
+    from kvzip_amd.template import template
+    d = tmp_path / "Qwen2.5-tiny"
+    tiny_model(family="qwen2").save_pretrained(str(d))
+    m = ModelKVzip(str(d), tokenizer=_ByteTokenizer(), max_new_tokens=4, cache_kwargs=dict(verbose=False))
+    assert m.name == "Qwen2.5-tiny" and m.sys_prompt_ids.shape[1] == len(template(m.name, "qa")[0].encode())
+    m.model.to(DEV)
+    m.device = torch.device(DEV)
+    m.set_chat_template()
+    kv = m.prefill("some context to compress " * 8, prefill_chunk_size=64)
+    assert kv.sink == m.sys_prompt_ids.shape[1] and kv.score[0].shape[-1] == kv.ctx_len
+    kv.prune(0.5)
+    assert isinstance(m.generate("what is it?", kv=kv), str)

@@ -98,6 +98,43 @@ def test_self_task_builds_repeat_prompts():
     assert r0.shape[1] - 100 == 5 and r1.shape[1] - 100 == 14
 
 
+def test_template_strings_equal_reference_outputs():
+    """template(name, task) returns exactly what the reference's model/template.py:5-33 returns (fixture g8 holds its outputs,
+    generated by oracle/gen_golden.py): with a real tokenizer these strings decide the sink length and the prompts."""
+    import json
+    import os
+    from conftest import GOLDEN
+    want = json.load(open(os.path.join(GOLDEN, "g8_templates.json")))
+    assert len(want) == 30
+    for key, (prefix, postfix) in want.items():
+        name, task = key.split("|")
+        assert template(name, task) == (prefix, postfix), key
+
+
+def test_load_head_score_is_a_stride0_view_and_save_layout(tmp_path):
+    """load_head_score: element-wise maximum over a model's files, expanded over the context WITHOUT materialising it
+    (reference model/wrapper.py:40-58); the file stem follows the reference's name mapping."""
+    from kvzip_amd.wrapper import head_score_name, load_head_score
+    assert head_score_name("Qwen2.5-7B-Instruct-1M") == "qwen2.5-7b"
+    assert head_score_name("Llama-3.1-8B-Instruct") == "llama3.1-8b" and head_score_name("tiny") == "tiny"
+    a = torch.rand(3, 2).half()
+    b = torch.rand(3, 2).half()
+    torch.save(a, tmp_path / "qwen2.5-14b-squad-0.pt")
+    torch.save(b.unsqueeze(0), tmp_path / "qwen2.5-14b-scbench_kv-3.pt")  # the reference squeezes
+    s = load_head_score("Qwen2.5-14B-Instruct-1M", 1 << 20, str(tmp_path), "cpu")
+    assert s.shape == (3, 1, 2, 1 << 20) and s.stride(-1) == 0
+    assert torch.equal(s[:, 0, :, 0], torch.maximum(a, b))
+    with pytest.raises(FileNotFoundError):
+        load_head_score("nothing", 8, str(tmp_path), "cpu")
+
+
+def test_tiny_api_cuda_alias_is_the_native_op():
+    """`from tiny_api_cuda import update_flatten_view` (reference attention/kvcache.py:10) resolves to the HIP-backed op."""
+    import tiny_api_cuda
+    from kvzip_amd import ops
+    assert tiny_api_cuda.update_flatten_view is ops.update_flatten_view
+
+
 def test_template_strings():
     for name in ("Qwen2.5-7B-Instruct-1M", "Llama-3.1-8B-Instruct", "Qwen3-8B", "tiny"):
         prefix, postfix = template(name, "qa")

@@ -91,6 +91,24 @@ def test_head_score_known_answers():
         assert g[f"{name}/thres/1000/0.6"][0] == thres
 
 
+def test_threshold_heads_equals_expanded_threshold():
+    """oracle.threshold_heads (no expansion: rank idx // N on the [L,Hkv] values) is pinned by the reference's results on the
+    expanded tensor (g4) and agrees with oracle.threshold on the expanded tensor for other N / ratios, ties included."""
+    g = load_golden("g4_head_score.npz")
+    for name in ("qwen2.5-14b", "qwen2.5-7b", "llama3.1-8b"):
+        hs = from_bits(g[f"{name}/head_score"], bool(g[f"{name}/is_bf16"][0]))
+        for ctx_len in (64, 1000):
+            for r in (0.3, 0.6, 0.9):
+                kept, t = orc.threshold_heads(hs, ctx_len, r)
+                assert np.array_equal(kept.numpy(), g[f"{name}/kept/{ctx_len}/{r!r}"])
+                assert t == g[f"{name}/thres/{ctx_len}/{r!r}"][0]
+        for ctx_len in (1, 7, 333):
+            for r in (0.0, 1e-9, 0.05, 0.5, 0.999, 1.0, 1.3):
+                kept, t = orc.threshold_heads(hs, ctx_len, r)
+                valid, t2 = orc.threshold(hs.unsqueeze(-1).expand(-1, -1, ctx_len).unsqueeze(1), r)
+                assert torch.equal(valid[:, 0, :, 0], kept) and t == t2, (name, ctx_len, r)
+
+
 @pytest.mark.parametrize("tag", ["f16_pair", "bf16_pair", "f16_uniform"])
 def test_cache_life_cycle_golden(tag):
     """score -> prune -> prepare_init -> append/prepare x3 -> slice, against the reference's EvictCache run."""
