@@ -47,7 +47,7 @@ template <> struct Mfma32<__bf16> {
 
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
 #ifndef KVZ_PB_WAVES
-#define KVZ_PB_WAVES 4
+#define KVZ_PB_WAVES 8   // round 2: one 8-wave block per CU (three 32-KiB row-tile buffers; 4 LDS-DMA pieces per wave and tile)
 #define KVZ_PB_OCC 2
 #endif
 constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
@@ -249,6 +249,21 @@ __device__ static inline void lds_dma16(const void* gsrc, const char* lds_dst /*
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)(lds_dst));
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");
 }
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no 64-bit VALU address arithmetic,
+// half the address registers); the LDS destination is given as a BYTE ADDRESS in LDS (an integer: a generic pointer costs a
+// null-checked address-space cast per piece)
+__device__ static inline uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lptr_t)(p); }
+__device__ static inline void lds_dma16a(const char* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte /* wave-uniform */) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_byte);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    // (readfirstlane returns a signed int: widen through uint32_t, a sign-extended low word would wipe out the high word)
+    const uint64_t bs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(bs), "s"(la) : "memory");
+}
+__device__ static inline void lds_dma16s(const char* sbase /* wave-uniform */, uint32_t voff, const char* lds_dst /* wave-uniform */) {
+    lds_dma16a(sbase, voff, lds_addr(lds_dst));
+}
 // all LDS-DMA of this wave has landed (the compiler does not count the assembly loads: its own vmcnt waits can only
 // become more conservative, never weaker, because the counter retires in order)
 __device__ static inline void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -290,16 +305,16 @@ __device__ static inline uint32_t stage_lane_offset(int wave, int lane) {
     return (uint32_t)(row * C::ROW_BYTES + chunk * 16);
 }
 template <int D, int NW>
-__device__ static inline void stage_tile_linear(char* buf, const char* base, uint32_t lane_off, int wave) {
+__device__ static inline void stage_tile_linear_a(uint32_t lds_byte /* of the buffer */, const char* base, uint32_t lane_off, int wave) {
     typedef ScoreCfg<D> C;
     constexpr int INSTR = C::TILE_BYTES / 1024;
     constexpr int PER_WAVE = INSTR / NW;
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int ci = i * NW + wave;
-        const char* src = base + (size_t)i * NW * 1024 + lane_off;
-        lds_dma16(src, buf + ci * 1024);
-    }
+    for (int i = 0; i < PER_WAVE; ++i) lds_dma16a(base + (size_t)i * NW * 1024, lane_off, lds_byte + (uint32_t)((i * NW + wave) * 1024));
+}
+template <int D, int NW>
+__device__ static inline void stage_tile_linear(char* buf, const char* base, uint32_t lane_off, int wave) {
+    stage_tile_linear_a<D, NW>(lds_addr(buf), base, lane_off, wave);
 }
 
 // ---- pass A: per-query-row softmax statistics ------------------------------------------------------
@@ -330,6 +345,12 @@ constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
 constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
+#ifndef KVZ_PB_V2
+#define KVZ_PB_V2 1                             // same for the column-maximum kernel
+#endif
+#ifndef KVZ_PA_V2
+#define KVZ_PA_V2 1                             // 1: software-pipelined row-statistics kernel (round 2); 0: round-1 kernel
+#endif
 
 // keys of the virtual sequence  sink ++ ctx chunk ++ repeat chunk  ->  rows of the cache (slow, per-lane path)
 struct KeyMap {
@@ -680,6 +701,580 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
     }
 }
 
+// ---- pass A, software-pipelined form (round 2) ------------------------------------------------------------------------
+// Same tiling, staging, static schedule and hand-over protocol as score_rowstat_kernel; what changes is the instruction
+// stream of a wave.  The matrix chain of 32-key block b+1 is issued INSIDE the epilogue of block b, one MFMA per group of
+// ~9-18 VALU instructions (groups are pinned with sched_barrier): a wave no longer alternates 256 cycles of matrix pipe
+// with ~500 cycles of VALU, it keeps both busy, and its partner on the SIMD fills the dependency stalls of the chain.
+// The epilogue itself is cut from ~136 to ~80 VALU instructions per 32x32 block:
+//   * no running-maximum tree: the exponentials are taken against a REFERENCE m_ref (a 16-bit value, so x - m_ref stays
+//     exact) that is only moved when a block's sum of exponentials exceeds 2^16 (cold path: maximum tree, rescale,
+//     redo of the block); the first block of every item takes that path once and sets m_ref to its own maximum.
+//     Softmax is shift invariant: pass B uses (x - m_ref) - log(sum exp(x - m_ref)), m_ref need not be the maximum;
+//   * accumulators are not cleared (the first MFMA of a chain takes the constant 0 as C);
+//   * fp16: rounding chain and exponent argument of FOUR logits are one assembly block of 8 instructions ordered so that
+//     every consumer of a 16-bit (dst_sel) write is at least one instruction behind it (no s_nop).
+// Placement of the KK MFMAs of a chain over the 8 half-groups of a pipeline step (half-group = 2 x quad index + half).
+// KVZ_SCHED 1 (default): the chain ends one half-group early - the next step starts by reading this accumulator, and a chain
+// that ends with the step makes it wait for the last MFMA (the compiler pads 12 wait states) - by issuing the first two
+// MFMAs back to back (dependent MFMAs issued back to back take the accumulator forwarding path).
+// KVZ_SCHED 0: one MFMA per half-group.
+#ifndef KVZ_SCHED
+#define KVZ_SCHED 1
+#endif
+#ifndef KVZ_PRIO          // 1: the second-dispatched half of a block gets priority in every other step (it loses VALU arbitration by age)
+#define KVZ_PRIO 1
+#endif
+#ifndef KVZ_CHAIN_MIX16   // 1: second rounding of the chain by v_fma_mixlo/hi_f16 (round 1); 0: fp32 product + v_cvt_pk_f16_f32
+#define KVZ_CHAIN_MIX16 0
+#endif
+template <int KK> struct MfmaSched {
+    // first k-step and number of k-steps issued in half-group hg
+    __device__ static constexpr int first(int hg) {
+        if (KK == 8) return KVZ_SCHED ? (hg == 0 ? 0 : hg + 1) : hg;
+        return hg / 2;  // KK == 4: even half-groups only
+    }
+    __device__ static constexpr int count(int hg) {
+        if (KK == 8) return KVZ_SCHED ? (hg == 0 ? 2 : (hg == 7 ? 0 : 1)) : 1;
+        return (hg & 1) ? 0 : 1;
+    }
+};
+template <typename T, bool FAST>
+__device__ static inline void quad_args(float a0, float a1, float a2, float a3, uint32_t& xa, uint32_t& xb, float (&arg)[4],
+                                        float c, float rcp, float L2E /* multiplier of x */, float neg_ml2 /* addend */) {
+    if constexpr (std::is_same<T, _Float16>::value && FAST) {
+        xa = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a0, a1}, h2v));
+        xb = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a2, a3}, h2v));
+#if KVZ_CHAIN_MIX16
+        // second rounding by v_fma_mixlo/hi_f16 (quarter rate: 8 cycles each)
+        asm("v_fma_mixlo_f16 %[xa], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %[xb], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %[xa], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %[xb], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g0], %[xa], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
+            : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
+#else
+        // second rounding as fp32 product (v_fma_mix_f32 reads the half, half rate) + v_cvt_pk_f16_f32 (two per instruction):
+        // 6.6 instead of 8.1 cycles per logit.  The four products land in the argument registers, which the last four
+        // instructions then overwrite with the exponent arguments (every consumer is >= 2 instructions behind its producer).
+        asm("v_fma_mix_f32 %[g0], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_pk_f16_f32 %[xa], %[g0], %[g1]\n\t"
+            "v_cvt_pk_f16_f32 %[xb], %[g2], %[g3]\n\t"
+            "v_fma_mix_f32 %[g0], %[xa], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
+            : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
+#endif
+    } else {
+        const T x0 = round_chain_h<T, FAST>(a0, c, rcp), x1 = round_chain_h<T, FAST>(a1, c, rcp);
+        const T x2 = round_chain_h<T, FAST>(a2, c, rcp), x3 = round_chain_h<T, FAST>(a3, c, rcp);
+        xa = bits16(x0) | (bits16(x1) << 16);
+        xb = bits16(x2) | (bits16(x3) << 16);
+        arg[0] = __builtin_fmaf((float)x0, L2E, neg_ml2);
+        arg[1] = __builtin_fmaf((float)x1, L2E, neg_ml2);
+        arg[2] = __builtin_fmaf((float)x2, L2E, neg_ml2);
+        arg[3] = __builtin_fmaf((float)x3, L2E, neg_ml2);
+    }
+}
+// the four exponentials of a quad and their sums into the two partial sums of the row (one assembly block: left to the
+// compiler the additions are SLP-packed into v_pk_add_f32 with s_nop hazards and all exponentials sink to the end of the
+// step, away from the MFMAs they are meant to cover).  Every v_add is 4 instructions behind its v_exp (transcendental
+// forwarding hazard: 1 wait state).
+__device__ static inline void quad_sum(const float (&arg)[4], float& ps0, float& ps1) {
+    float e0, e1, e2, e3;
+    asm("v_exp_f32 %[e0], %[a0]\n\t"
+        "v_exp_f32 %[e1], %[a1]\n\t"
+        "v_exp_f32 %[e2], %[a2]\n\t"
+        "v_exp_f32 %[e3], %[a3]\n\t"
+        "v_add_f32 %[p0], %[p0], %[e0]\n\t"
+        "v_add_f32 %[p1], %[p1], %[e1]\n\t"
+        "v_add_f32 %[p0], %[p0], %[e2]\n\t"
+        "v_add_f32 %[p1], %[p1], %[e3]"
+        : [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3), [p0] "+v"(ps0), [p1] "+v"(ps1)
+        : [a0] "v"(arg[0]), [a1] "v"(arg[1]), [a2] "v"(arg[2]), [a3] "v"(arg[3]));
+}
+// maximum of the 16 chain results held as 8 packed registers
+template <typename T> __device__ static inline float max_packed16(const uint32_t (&xp)[8]) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        h2v m = __builtin_bit_cast(h2v, xp[0]);
+#pragma unroll
+        for (int p = 1; p < 8; ++p) m = __builtin_elementwise_max(m, __builtin_bit_cast(h2v, xp[p]));
+        return fmaxf((float)m[0], (float)m[1]);
+    } else {
+        float m = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) m = fmaxf(m, fmaxf(pair_lo<T>(xp[p]), pair_hi<T>(xp[p])));
+        return m;
+    }
+}
+
+constexpr float PA2_SUM_LIMIT = 65536.f;
+constexpr float PA2_SUM_LOW = 9.5367431640625e-07f;  // 2^-20: lower bound for the FIRST block of an item (reference still 0)
+
+// optional in-kernel timeline (-DKVZ_TRACE=1, tools/trace2.py): s_memtime stamps of ONE block per 32, all 8 waves, 8 stamps per
+// tile = start of the four steps, arrival at / release from the hand-over barrier, end of the hand-over, end of the tile
+#ifndef KVZ_TRACE
+#define KVZ_TRACE 0
+#endif
+
+#if KVZ_TRACE
+__device__ unsigned long long g_trace2[8 * 8 * 40 * 8];
+#define KVZ_STAMP(i) do { ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KVZ_STAMP(i) do { } while (0)
+#endif  // a block whose exponentials (vs the reference) sum to more moves the reference
+
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a) {
+    constexpr int NWAVES = PA_WAVES;
+    typedef ScoreCfg<D> C;
+    typedef typename Mfma32<T>::v8 v8;
+    constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
+    constexpr int RING = 3;  // key-tile buffers: tile p of the block's stream lives in buffer p % 3 (160 KiB of LDS at D = 128)
+    __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
+    char* const qarea = lds + RING * C::TILE_BYTES;
+    constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
+    constexpr float L2E = 1.44269504088896340736f;
+    constexpr int NB = SC_TILE / 32;  // 32-key blocks per tile
+    static_assert(NB == 4, "the block pipeline alternates two register sets over an even number of blocks per tile");
+
+    const int R = a.G * a.q_len;
+    const int KT = a.sink + a.m + a.q_len;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int diag0 = a.sink + a.m;  // first key that can be masked for some row
+    const int off_ctx = a.start - a.sink;                       // virtual -> cache row, ctx segment
+    const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
+    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
+
+    // ---- work items and static snake schedule: identical to score_rowstat_kernel ----
+    const int RT = (R + PA_ROWS - 1) / PA_ROWS;
+    const int per_z = RT * a.n_kv_heads;
+    const int nitems = per_z * a.key_splits;
+    struct Item { int k, h, rt, z, t_lo, t_hi; };
+    auto decode = [&](int i) __attribute__((always_inline)) -> Item {
+        Item it;
+        it.k = 0;
+        it.z = i / per_z;
+        const int rem = i - it.z * per_z;
+        it.rt = rem / a.n_kv_heads;
+        it.h = rem - it.rt * a.n_kv_heads;
+        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
+        const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
+        const int ntiles = (min(KT, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
+        it.t_lo = it.z * SC_KSPLIT_TILES;
+        it.t_hi = min(ntiles, it.t_lo + SC_KSPLIT_TILES);
+        return it;
+    };
+    const int G_ = gridDim.x;
+    auto item_from = [&](int k) -> Item {
+        Item it;
+        it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
+        for (;; ++k) {
+            const int i = (k & 1) ? (k + 1) * G_ - 1 - (int)blockIdx.x : k * G_ + (int)blockIdx.x;
+            if (k * G_ >= nitems) return it;
+            if (i >= nitems) continue;
+            Item c = decode(i);
+            if (c.t_lo < c.t_hi) {
+                c.k = k;
+                return c;
+            }
+        }
+    };
+    auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
+    // tiles (128 consecutive virtual keys) that lie inside ONE segment are consecutive rows of the cache: [tc_lo, tc_hi) inside
+    // the ctx chunk, [tr_lo, tr_hi) inside the repeat chunk, [0, ts_hi) inside the sink; every other tile straddles a boundary
+    // (or the end) and takes the per-lane path
+    const int ts_hi = a.sink / SC_TILE;
+    const int tc_lo = (a.sink + SC_TILE - 1) / SC_TILE, tc_hi = (a.sink + a.m) / SC_TILE;
+    const int tr_lo = (a.sink + a.m + SC_TILE - 1) / SC_TILE, tr_hi = KT / SC_TILE;
+    const uint32_t lds0 = lds_addr(lds);
+    const char* const kbase = reinterpret_cast<const char*>(a.k);
+    const int64_t khs = a.k_head_stride * 2;
+    auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
+        const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
+        const char* kh = kbase + (int64_t)h * khs;
+        const int kv0 = t * SC_TILE;
+        int off = 0;
+        bool linear = true;
+        if (t >= tc_lo && t < tc_hi) off = off_ctx;
+        else if (t >= tr_lo && t < tr_hi) off = off_rep;
+        else if (t >= ts_hi) linear = false;
+        if (linear) {
+            stage_tile_linear_a<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
+        } else {  // (inlined: a call would open with s_waitcnt vmcnt(0) and drain the tiles in flight)
+            constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int ci = i * NWAVES + wave;  // wave-uniform 1-KiB piece of the tile
+                const int row = ci * ROWS_PER_INSTR + lane / C::CPR;
+                const int pch = lane % C::CPR;
+                const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                const int kv = min(kv0 + row, KT - 1);
+                const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
+                lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
+            }
+        }
+    };
+    auto stage_q = [&](const Item& it) __attribute__((always_inline)) {
+        // 32 rows per group, same swizzle as a key tile; rows beyond R shadow row R-1.  The rows of a group lie in at most
+        // two query heads of the KV head: one scalar division per group, none per lane.  (Inlined: a call drains the DMA queue.)
+        const char* qh = reinterpret_cast<const char*>(a.q) + (int64_t)it.h * a.G * a.q_head_stride * 2;
+        const int64_t hs = a.q_head_stride * 2;
+        constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            const uint32_t buf = lds0 + (uint32_t)(RING * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
+            const int r0 = it.rt * PA_ROWS + (wave * PA_RG + g) * 32;
+            const int rc0 = min(r0, R - 1);
+            const int g0 = rc0 / a.q_len, qi0 = rc0 - g0 * a.q_len;  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+                const int row = i * ROWS_PER_INSTR + lane / C::CPR;
+                const int pch = lane % C::CPR;
+                const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                int gg = g0, qi = qi0 + min(row, R - 1 - rc0);  // clamp to the last row
+                if (a.q_len >= 32) {
+                    if (qi >= a.q_len) { qi -= a.q_len; ++gg; }
+                } else {  // (tiny chunks only: a group of 32 rows spans several query heads)
+                    gg += qi / a.q_len;
+                    qi = qi % a.q_len;
+                }
+                lds_dma16a(qh, (uint32_t)(gg * (int)hs + qi * C::ROW_BYTES + chunk * 16), buf + (uint32_t)(i * 1024));
+            }
+        }
+    };
+    FragAddr<D> fa0;
+    fa0.init(lds, l31, half);
+    auto read_q = [&](v8 (&dst)[PA_RG][C::KK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            FragAddr<D> fq;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) fq.a[kk] = fa0.a[kk] + (uint32_t)(RING * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
+            u32x4 tmp[C::KK];
+            frag_load<D>(tmp, fq, 0);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) dst[g][kk] = __builtin_bit_cast(v8, tmp[kk]);
+        }
+    };
+    struct Rows { int r[PA_RG], limit[PA_RG]; };
+    auto rows_of = [&](const Item& it) __attribute__((always_inline)) -> Rows {
+        Rows w;
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            w.r[g] = it.rt * PA_ROWS + (wave * PA_RG + g) * 32 + l31;
+            const int rc = min(w.r[g], R - 1);
+            w.limit[g] = a.sink + a.m + rc % a.q_len;  // key j (virtual index) is visible to query i iff j <= sink + m + i  (score.py:67-85)
+        }
+        return w;
+    };
+    // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates
+    auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
+        frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    Item cur = item_from(0);
+    if (!valid(cur)) return;
+    Item nxt = item_from(cur.k + 1);
+    bool sq_in_next = false, sq_done = false;
+    int sq_t = cur.t_lo;
+    auto sq_stage = [&](int b) __attribute__((always_inline)) {
+        stage(b, sq_in_next ? nxt.h : cur.h, sq_t);
+        ++sq_t;
+        if (sq_t >= (sq_in_next ? nxt.t_hi : cur.t_hi)) {
+            if (!sq_in_next && valid(nxt)) {
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            } else {
+                sq_done = true;
+            }
+        }
+    };
+    stage_q(cur);
+    sq_stage(0);
+    int staged = 1;  // tiles of the block's stream staged so far (stream position p -> buffer p % 3)
+    if (!sq_done) {
+        sq_stage(1);
+        staged = 2;
+    }
+    stage_wait();
+    block_barrier();
+    v8 bq[PA_RG][C::KK];
+    read_q(bq);
+    u32x4 fr[2][C::KK];
+    load_frags(fr[0], I0{}, I0{});
+    load_frags(fr[1], I0{}, I1{});
+#pragma unroll
+    for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
+    if (valid(nxt)) stage_q(nxt);
+    Rows rows = rows_of(cur);
+
+    int pbuf = 0;  // buffer of the tile being computed (= sp % 3)
+    int sp = 0;    // its position in the block's stream
+    int t = cur.t_lo;
+    float m_ref[PA_RG], nml2_ref[PA_RG], l_run[PA_RG];  // reference (16-bit value), -fl(reference * log2e), sum of 2^(x*log2e + nml2)
+    int wmin[PA_RG];
+    auto start_item = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            m_ref[g] = 0.f;  // reference 0 until a block says otherwise: its sum of exponentials leaves [2^-20, 2^16] (first block
+            nml2_ref[g] = 0.f;  // of the item: both bounds, later blocks: the upper one) -> cold path, reference = block maximum
+            l_run[g] = 0.f;
+            int lo = rows.limit[g];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o, 64));
+            wmin[g] = __builtin_amdgcn_readfirstlane(lo);  // keys <= wmin are visible to every row of the group
+        }
+    };
+    start_item();
+
+#if KVZ_TRACE
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool tracing = (blockIdx.x % 32 == 5) && lane == 0;
+    unsigned long long* tr = g_trace2 + (((blockIdx.x / 32) % 8) * 8 + wave) * (40 * 8);
+    int tp = 0;
+#endif
+    f16v acc[2][PA_RG];  // accumulators of block kb (index kb & 1)
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // One pipeline step: the matrix chains of the NEXT block (fragment set frn -> accn) are issued inside the epilogue of
+    // the CURRENT block (accc, first key k0).  WITH_MFMA = false drains the pipeline (last block of an item).  `hook` runs
+    // after the first quarter of the step (fragment prefetch / tile hand-over): by then the last MFMA of the previous step
+    // has read the fragment registers that the prefetch overwrites.
+    auto step = [&](f16v (&accn)[PA_RG], const f16v (&accc)[PA_RG], const u32x4 (&frn)[C::KK], int k0, float ps_low, auto mask_tag,
+                    auto mfma_tag, auto&& hook) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
+        uint32_t xp[PA_RG][8];
+        float ps0[PA_RG], ps1[PA_RG];
+        int rel[PA_RG];
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            ps0[g] = ps1[g] = 0.f;
+            rel[g] = rows.limit[g] - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) of accumulator i is visible iff <= rel
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float arg[PA_RG][4];
+            // -- first half: one MFMA per chain, conversions + rounding chain + exponent arguments of 4 logits per row group
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WITH_MFMA) {
+#pragma unroll
+                for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd); ++c)
+#pragma unroll
+                    for (int g = 0; g < PA_RG; ++g) {
+                        const int kk = MfmaSched<C::KK>::first(2 * qd) + c;
+                        accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = qd * 4 + j;
+                    v[j] = (!MASK || (i & 3) + 8 * (i >> 2) <= rel[g]) ? accc[g][i] : -INFINITY;  // -inf survives the chain
+                }
+                quad_args<T, FAST>(v[0], v[1], v[2], v[3], xp[g][2 * qd], xp[g][2 * qd + 1], arg[g], a.c, a.rcp, L2E, nml2_ref[g]);
+            }
+            // -- second half: (second MFMA,) the four exponentials and their sums
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WITH_MFMA) {
+#pragma unroll
+                for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd + 1); ++c)
+#pragma unroll
+                    for (int g = 0; g < PA_RG; ++g) {
+                        const int kk = MfmaSched<C::KK>::first(2 * qd + 1) + c;
+                        accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], accn[g]);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g) quad_sum(arg[g], ps0[g], ps1[g]);
+            if (qd == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                hook();
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            float ps = ps0[g] + ps1[g];
+            if (__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0) {  // wave-uniform and rare: move the reference, redo
+                asm volatile("" ::: "memory");                                                 // (keeps it a branch)
+                const float tmax = max_packed16<T>(xp[g]);
+                // up: a logit far above the reference; down (first block of an item only, nothing summed yet): all logits far below
+                // it.  A lane whose 16 logits are all masked keeps its state (tmax = -inf).
+                if (tmax > m_ref[g] || (l_run[g] == 0.f && tmax > -INFINITY)) {
+                    const float nml2_new = -(tmax * L2E);
+                    l_run[g] *= __builtin_amdgcn_exp2f(nml2_new - nml2_ref[g]);
+                    m_ref[g] = tmax;
+                    nml2_ref[g] = nml2_new;
+                }
+                ps = 0.f;
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    ps += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xp[g][p]), L2E, nml2_ref[g])) +
+                          __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xp[g][p]), L2E, nml2_ref[g]));
+            }
+            l_run[g] += ps;
+        }
+    };
+    // matrix chains of the first block of an item (nothing to overlap them with)
+    auto chain0 = [&](f16v (&accn)[PA_RG], const u32x4 (&frn)[C::KK]) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk)
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g)
+                accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    bool next_ready = false;
+    // Hand-over in the third step of a tile (B = its buffer).  Every fragment of the tile has been read by now (block 3 in the
+    // second step).  With three buffers the tile two positions ahead goes into the buffer that the PREVIOUS hand-over freed,
+    // so its DMA is issued BEFORE the barrier: a wave that arrives early issues while the others still compute, and after
+    // the barrier only the fragment reads remain.  The counted wait leaves exactly the pieces issued here in flight.
+    auto turnover = [&](auto b_tag) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_tag)::value;
+        constexpr int B1 = (B + 1) % RING, B2 = (B + 2) % RING;
+        int newer = 0;  // tiles staged here that come AFTER the next tile
+        if (staged < sp + 2 && !sq_done) {  // the stream was starved (items of a single tile): the next tile itself is missing
+            sq_stage(B1);
+            ++staged;
+        }
+        if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
+            sq_stage(B2);
+            ++staged;
+            newer = 1;
+        }
+        KVZ_STAMP(4);
+        if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // the next tile (and older pieces) landed
+        else stage_wait();
+        block_barrier();  // ... everybody's part has, and nobody reads tile B any more
+        KVZ_STAMP(5);
+        next_ready = staged >= sp + 2;
+        if (next_ready) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
+        KVZ_STAMP(6);
+    };
+    auto tile_steps = [&](auto b_tag, auto mask_tag) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_tag)::value;
+        constexpr int B1 = (B + 1) % RING;
+        const int k0 = t * SC_TILE;
+        KVZ_STAMP(0);
+#if KVZ_PRIO
+        // experiment: the second-dispatched half of the block loses VALU arbitration by age; give it priority in every other step
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+        step(acc[1], acc[0], fr[1], k0, (t == cur.t_lo) ? PA2_SUM_LOW : 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
+#if KVZ_PRIO
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(0);
+#endif
+        KVZ_STAMP(1);
+        step(acc[0], acc[1], fr[0], k0 + 32, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+        KVZ_STAMP(2);
+#if KVZ_PRIO
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+        step(acc[1], acc[0], fr[1], k0 + 64, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
+#if KVZ_PRIO
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(0);
+#endif
+        KVZ_STAMP(3);
+        // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
+        // (one variant less of every tile body; the matrix pipe has the slack)
+        step(acc[0], acc[1], fr[0], k0 + 96, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) {
+            if (next_ready) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
+        });
+        KVZ_STAMP(7);
+#if KVZ_TRACE
+        if (tracing && tp < 40) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tr[tp * 8 + i] = ts[i];
+            ++tp;
+        }
+#endif
+    };
+    auto tile_dispatch = [&](auto b_tag) __attribute__((always_inline)) {
+        int wm = wmin[0];
+#pragma unroll
+        for (int g = 1; g < PA_RG; ++g) wm = min(wm, wmin[g]);
+        const bool masked = t * SC_TILE + SC_TILE - 1 > wm;  // some key of the tile is hidden from some row of this wave
+        if (masked) tile_steps(b_tag, std::true_type{});
+        else tile_steps(b_tag, std::false_type{});
+    };
+    (void)diag0;
+
+    chain0(acc[0], fr[0]);
+    while (true) {
+        if (pbuf == 0) tile_dispatch(I0{});
+        else if (pbuf == 1) tile_dispatch(I1{});
+        else tile_dispatch(I2{});
+        pbuf = (pbuf == RING - 1) ? 0 : pbuf + 1;
+        ++sp;
+        ++t;
+        if (t < cur.t_hi) continue;  // (acc[0] already holds block 0 of the next tile)
+
+        // ---- item finished: partial statistics of this key slice (reference m_ref, sum relative to fl(m_ref*log2e)) ----
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            // merge the two half-waves (they saw disjoint keys of the same query row)
+            const float m_o = __shfl_xor(m_ref[g], 32, 64);
+            const float nml2_o = __shfl_xor(nml2_ref[g], 32, 64);
+            const float l_o = __shfl_xor(l_run[g], 32, 64);
+            const float M = fmaxf(m_ref[g], m_o);
+            const float NML2 = (m_ref[g] >= m_o) ? nml2_ref[g] : nml2_o;
+            const float Lp = l_run[g] * __builtin_amdgcn_exp2f(NML2 - nml2_ref[g]) + l_o * __builtin_amdgcn_exp2f(NML2 - nml2_o);
+            if (half == 0 && rows.r[g] < R) {
+                // (stored from assembly: a store the compiler knows about makes it wait on the counter that also holds the DMA)
+                float2* dst = a.stats + ((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + rows.r[g];
+                const float2 val = make_float2(M, Lp);
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+            }
+        }
+        if (!valid(nxt)) break;
+        // ---- switch to the next item: fragments of its first two blocks are in registers, its query rows landed before the
+        // last hand-over ----
+        cur = nxt;
+        nxt = item_from(cur.k + 1);
+        t = cur.t_lo;
+        rows = rows_of(cur);
+        read_q(bq);
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // rows in registers: the area is free again
+        if (valid(nxt)) stage_q(nxt);
+        if (sq_in_next) {  // the cursor was already inside the item that is now current
+            sq_in_next = false;
+            if (sq_done && valid(nxt)) {
+                sq_done = false;
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            }
+        }
+        start_item();
+        chain0(acc[0], fr[0]);
+    }
+}
+
 // merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
 // 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).  Only the slices below the causal limit of the row's tile exist.
 __global__ void score_merge_stats_kernel(ScoreArgs a, int R, int64_t rows_total) {
@@ -860,6 +1455,218 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax_kernel(Sco
     }
 }
 
+// ---- pass B, software-pipelined form (round 2): the matrix chain of 32-row block b+1 rides inside the epilogue of block b -----
+// (same tiling and staging as score_colmax_kernel).  Epilogue of four logits: one assembly block with the rounding chain and
+// x - m_r (8 instructions, see quad_args), one with - log l_r and the running maxima; blocks alternate between "hold" and
+// "v_max3(best, hold, t)" so that two blocks share one maximum instruction per key.
+__device__ static inline void quad_hold(const float (&t)[4], float ll, float& h0, float& h1, float& h2, float& h3) {
+    asm("v_sub_f32 %[h0], %[t0], %[ll]\n\t"
+        "v_sub_f32 %[h1], %[t1], %[ll]\n\t"
+        "v_sub_f32 %[h2], %[t2], %[ll]\n\t"
+        "v_sub_f32 %[h3], %[t3], %[ll]"
+        : [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3)
+        : [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]), [ll] "v"(ll));
+}
+__device__ static inline void quad_max(float (&t)[4], float ll, float& b0, float& b1, float& b2, float& b3, float h0, float h1,
+                                       float h2, float h3) {
+    asm("v_sub_f32 %[t0], %[t0], %[ll]\n\t"
+        "v_sub_f32 %[t1], %[t1], %[ll]\n\t"
+        "v_sub_f32 %[t2], %[t2], %[ll]\n\t"
+        "v_sub_f32 %[t3], %[t3], %[ll]\n\t"
+        "v_max3_f32 %[b0], %[b0], %[h0], %[t0]\n\t"
+        "v_max3_f32 %[b1], %[b1], %[h1], %[t1]\n\t"
+        "v_max3_f32 %[b2], %[b2], %[h2], %[t2]\n\t"
+        "v_max3_f32 %[b3], %[b3], %[h3], %[t3]"
+        : [t0] "+v"(t[0]), [t1] "+v"(t[1]), [t2] "+v"(t[2]), [t3] "+v"(t[3]), [b0] "+v"(b0), [b1] "+v"(b1), [b2] "+v"(b2),
+          [b3] "+v"(b3)
+        : [h0] "v"(h0), [h1] "v"(h1), [h2] "v"(h2), [h3] "v"(h3), [ll] "v"(ll));
+}
+
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(ScoreArgs a) {
+    constexpr int NWAVES = PB_WAVES;
+    constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
+    typedef ScoreCfg<D> C;
+    typedef typename Mfma32<T>::v8 v8;
+    constexpr int RING = 3;  // query-row tile p of the block's slice lives in buffer p % 3 (see score_rowstat2_kernel)
+    __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + RING * SC_TILE * 8];
+    char* const lstat = lds + RING * C::TILE_BYTES;
+    constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile (+1 for wave 0: statistics)
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    const int SH = a.row_splits * a.n_kv_heads;
+    const int bj = blockIdx.x % SH;            // (row slice, head)
+    const int ctile = blockIdx.x / SH;         // ctx-key tile
+    const int ysplit = bj % a.row_splits;
+    const int h = bj / a.row_splits;
+    const int R = a.G * a.q_len;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // stationary operand: 32 ctx keys per wave as the A operand (result row = key, 16 keys per lane)
+    const int j0 = ctile * SC_COLS + wave * 32;
+    v8 ak[C::KK];
+    {
+        const int j = min(j0 + l31, a.m - 1);
+        const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + j) * D) * 2 + half * 16;
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk)
+            ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for these loads belongs here
+    }
+    const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
+    const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
+    const int t_begin = ysplit * per;
+    const int t_end = min(total_tiles, t_begin + per);
+
+    const char* qbase = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * a.q_head_stride * 2;
+    auto rowptr = [&](int r) -> const char* {
+        r = min(r, R - 1);
+        const int g = r / a.q_len;
+        const int qi = r - g * a.q_len;
+        return qbase + ((int64_t)g * a.q_head_stride + (int64_t)qi * D) * 2;
+    };
+    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
+    const char* stats_h = reinterpret_cast<const char*>(a.stats + (int64_t)h * a.stats_stride);
+    const uint32_t lds0 = lds_addr(lds);
+    // staging cursor: tiles are staged in order, so the (query head, row in head) of a tile's first row is advanced
+    // incrementally (one scalar division per block instead of one per tile)
+    int sg_t = t_begin, sg_g = (t_begin * SC_TILE) / a.q_len, sg_qi = t_begin * SC_TILE - sg_g * a.q_len;
+    auto stage = [&](int b) __attribute__((always_inline)) {  // stages tile sg_t into buffer b and advances the cursor
+        const int t = sg_t;
+        const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
+        if (wave == 0) lds_dma16a(stats_h + (int64_t)t * SC_TILE * 8, (uint32_t)(lane * 16), lds0 + (uint32_t)(RING * C::TILE_BYTES + b * SC_TILE * 8));
+        const int r0 = t * SC_TILE;
+        if (r0 + SC_TILE <= R && sg_qi + SC_TILE <= a.q_len) {
+            stage_tile_linear_a<D, NWAVES>(dst, qbase + ((int64_t)sg_g * a.q_head_stride + (int64_t)sg_qi * D) * 2, lane_off, wave);
+        } else {
+            stage_tile<D, NWAVES>(lds + b * C::TILE_BYTES, r0, rowptr, wave, lane);
+        }
+        ++sg_t;
+        sg_qi += SC_TILE;
+        while (sg_qi >= a.q_len) { sg_qi -= a.q_len; ++sg_g; }
+    };
+    FragAddr<D> fa0;
+    fa0.init(lds, l31, half);
+    auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
+        frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
+    };
+
+    float best[16], hold[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) best[i] = hold[i] = -INFINITY;
+
+    if (t_begin < t_end) {
+        stage(0);
+        if (t_begin + 1 < t_end) stage(1);
+        stage_wait();
+        block_barrier();
+        u32x4 fr[2][C::KK];
+        load_frags(fr[0], I0{}, I0{});
+        load_frags(fr[1], I0{}, I1{});
+        f16v acc[2];
+        const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int t = t_begin;
+
+        // one pipeline step: chain of the next block (frn -> accn) inside the epilogue of the current block (accc); ODD blocks
+        // fold the held values of the previous block and their own into the running maxima
+        auto step = [&](f16v& accn, const f16v& accc, const u32x4 (&frn)[C::KK], float2 st, auto odd_tag, auto mfma_tag,
+                        auto&& hook) __attribute__((always_inline)) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
+            const float neg_mr = -st.x, ll = st.y;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float tv[4];
+                uint32_t xa, xb;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WITH_MFMA) {
+#pragma unroll
+                    for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd); ++c) {
+                        const int kk = MfmaSched<C::KK>::first(2 * qd) + c;
+                        accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), kk == 0 ? zero16 : accn);
+                    }
+                }
+                quad_args<T, FAST>(accc[4 * qd], accc[4 * qd + 1], accc[4 * qd + 2], accc[4 * qd + 3], xa, xb, tv, a.c, a.rcp, 1.0f, neg_mr);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WITH_MFMA) {
+#pragma unroll
+                    for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd + 1); ++c) {
+                        const int kk = MfmaSched<C::KK>::first(2 * qd + 1) + c;
+                        accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), accn);
+                    }
+                }
+                if constexpr (ODD)
+                    quad_max(tv, ll, best[4 * qd], best[4 * qd + 1], best[4 * qd + 2], best[4 * qd + 3], hold[4 * qd], hold[4 * qd + 1],
+                             hold[4 * qd + 2], hold[4 * qd + 3]);
+                else
+                    quad_hold(tv, ll, hold[4 * qd], hold[4 * qd + 1], hold[4 * qd + 2], hold[4 * qd + 3]);
+                if (qd == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    hook();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto tile_steps = [&](auto b_tag) __attribute__((always_inline)) {
+            constexpr int B = decltype(b_tag)::value;
+            constexpr int B1 = (B + 1) % RING, B2 = (B + 2) % RING;
+            float2 st[SC_TILE / 32];  // (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of the tile
+#pragma unroll
+            for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = *reinterpret_cast<const float2*>(lstat + (B * SC_TILE + kb * 32 + l31) * 8);
+            step(acc[1], acc[0], fr[1], st[0], std::false_type{}, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
+            step(acc[0], acc[1], fr[0], st[1], std::true_type{}, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+            step(acc[1], acc[0], fr[1], st[2], std::false_type{}, std::true_type{}, [&]() __attribute__((always_inline)) {
+                // hand-over: the tile two positions ahead goes into the buffer the previous hand-over freed, its DMA is issued
+                // BEFORE the barrier; the counted wait leaves exactly those pieces in flight
+                if (t + 2 < t_end) {
+                    stage(B2);
+                    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                } else {
+                    stage_wait();
+                }
+                block_barrier();  // the next tile has landed for everybody, every fragment of this tile has been read
+                if (t + 1 < t_end) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
+            });
+            // (after the last tile the chain issued here is not used)
+            step(acc[0], acc[1], fr[0], st[3], std::true_type{}, std::true_type{}, [&]() __attribute__((always_inline)) {
+                if (t + 1 < t_end) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
+            });
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) acc[0] = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[0][kk]), kk == 0 ? zero16 : acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int pb = 0; t < t_end; ++t, pb = (pb == RING - 1) ? 0 : pb + 1) {
+            if (pb == 0) tile_steps(I0{});
+            else if (pb == 1) tile_steps(I1{});
+            else tile_steps(I2{});
+        }
+    }
+    // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float b = best[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+        best[i] = b;
+    }
+    if (l31 == 0) {
+        float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (j < a.m) dst[j] = best[i];
+        }
+    }
+}
+
 template <typename T>
 __global__ void score_finalize_kernel(const float* __restrict__ colpart, int splits, int Hkv, int m, T* __restrict__ out,
                                       int64_t out_head_stride) {
@@ -882,7 +1689,7 @@ static inline int score_key_splits(int sink, int m, int q_len) {
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
     const int ctiles = (m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
-    int splits = 512 / (ctiles * Hkv);  // 256 CUs x 2 resident blocks: exactly one round when the shape allows
+    int splits = (PB_WAVES == 8 ? 256 : 512) / (ctiles * Hkv);  // one round of resident blocks (1 or 2 per CU) when the shape allows
     if (splits > rtiles) splits = rtiles;
     if (splits < 1) splits = 1;
     const int per = (rtiles + splits - 1) / splits;
@@ -981,7 +1788,11 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         const int items = (R + PA_ROWS - 1) / PA_ROWS * Hkv * a.key_splits;
         const int blocks = min(items, SC_PERSISTENT_BLOCKS);
         ProfScope ps("score_rowstat", stream);
+#if KVZ_PA_V2
+        hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
+#else
         hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
+#endif
     }
     KVZ_CHECK_LAUNCH("score_rowstat_kernel");
     {
@@ -993,7 +1804,11 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     {
         ProfScope ps("score_colmax", stream);
+#if KVZ_PB_V2
+        hipLaunchKernelGGL((score_colmax2_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+#else
         hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+#endif
     }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
@@ -1039,6 +1854,8 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     KVZ_REQUIRE(aligned16(q) && aligned16(k), KVZ_EINVAL, "kvz_score_chunk: q/k must be 16-byte aligned");
     KVZ_REQUIRE((q_head_stride * 2) % 16 == 0 && (k_head_stride * 2) % 16 == 0, KVZ_EINVAL,
                 "kvz_score_chunk: head strides must be multiples of 8 elements");
+    KVZ_REQUIRE((int64_t)G * q_head_stride * 2 < (1ll << 31) && (int64_t)klen * D * 2 < (1ll << 31), KVZ_EUNSUPPORTED,
+                "kvz_score_chunk: a KV head (and the query heads of its group) must span less than 2 GiB");
     KVZ_REQUIRE(ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink), KVZ_EWORKSPACE,
                 "kvz_score_chunk: workspace too small");
     ScoreArgs a{};
@@ -1096,3 +1913,9 @@ extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtyp
     KVZ_CHECK_LAUNCH("chain_probe_kernel");
     return KVZ_OK;
 }
+
+#if KVZ_TRACE
+extern "C" int kvz_debug_read_trace2(unsigned long long* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace2), bytes);
+}
+#endif
