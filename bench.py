@@ -282,6 +282,15 @@ def main(argv=None):
             Ks.append(randn(L, 1, Hkv, q_max, D))
             Vs.append(randn(L, 1, Hkv, q_max, D))
     cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    # per (input set, query length) the per-layer views handed to the cache object: what a forward pass would hand over as
+    # ready tensors; slicing them inside the timed loop would charge ~15 us of harness indexing to every (layer, chunk)
+    views = {}
+    for c, (st, en, q_len) in enumerate(chunks):
+        key = (c % pool if pool else 0, q_len)
+        if pool and key not in views:
+            p_ = c % pool
+            views[key] = ([Qs[p_][l][:, :, :q_len] for l in range(L)], [Ks[p_][l][:, :, :q_len] for l in range(L)],
+                          [Vs[p_][l][:, :, :q_len] for l in range(L)])
 
     period = max(1, args.prof_period)
     timing = {"on": False, "n": 0}
@@ -298,9 +307,9 @@ def main(argv=None):
             for c, (st, en, q_len) in enumerate(chunks):
                 kv.start_idx, kv.end_idx = st, en          # model/wrapper.py:238-244
                 seen = kv._seen_tokens
-                Qc, Kc, Vc = Qs[c % pool], Ks[c % pool], Vs[c % pool]
+                Qv, Kv, Vv = views[(c % pool, q_len)]
                 for l in range(L):
-                    k_all, _ = kv.update(Kc[l][:, :, :q_len], Vc[l][:, :, :q_len], l)  # attention/attn.py:44-48
+                    k_all, _ = kv.update(Kv[l], Vv[l], l)                               # attention/attn.py:44-48
                     # kernel timings: every `period`-th scoring call runs ALONE on the caller's stream, bracketed by hipEvents;
                     # all other calls overlap on the side streams (their kernels share the GPU, so their brackets would not
                     # measure a kernel)
@@ -310,7 +319,7 @@ def main(argv=None):
                         kv._wait_score()
                         kv._score_exclusive = True
                         lib.kvz_prof_enable(1)
-                    kv._get_score(Qc[l][:, :, :q_len], k_all, l)                        # attention/attn.py:53-54
+                    kv._get_score(Qv[l], k_all, l)                                      # attention/attn.py:53-54
                     if sample:
                         lib.kvz_prof_enable(0)
                         kv._score_exclusive = False

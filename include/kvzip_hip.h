@@ -77,6 +77,23 @@ int kvz_score_chunk(const void* q, int64_t q_head_stride,
                     void* out, int64_t out_head_stride,
                     void* ws, size_t ws_bytes, kvz_stream_t stream);
 
+/* Asynchronous form of a1 (no reference counterpart: the reference scores on the forward pass's own stream, attention/attn.py:53-54).
+ * The scores of a layer are a side product that nothing consumes before prune(), so the call runs on a SIDE stream:
+ *   record(ready[slot], caller); wait(side, ready[slot]); kvz_score_chunk(..., side); record(done[slot], side)
+ * and kvz_async_wait(handle, slot, stream) orders `stream` behind the scoring calls still pending in `slot` (slot < 0: all).
+ * A context is a set of host-side events (no device memory); slots are the caller's (typically one per layer).
+ * side == caller degenerates to kvz_score_chunk on that stream. */
+int kvz_async_create(int n_slots);   /* -> handle >= 0, or a negative KVZ_E* code */
+int kvz_async_destroy(int handle);
+int kvz_async_wait(int handle, int slot, kvz_stream_t stream);
+int kvz_score_chunk_async(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
+                          const void* q, int64_t q_head_stride,
+                          const void* k, int64_t k_head_stride, int klen,
+                          int sink, int start, int end, int q_len,
+                          int Hkv, int G, int D, int dtype,
+                          void* out, int64_t out_head_stride,
+                          void* ws, size_t ws_bytes);
+
 /* Test hook for the rounding chain of a1: out[i] = half( float(in[i]) / float(sqrt(D)) ) computed exactly as the
  * scoring kernels do (exact-reciprocal multiply when the host's exhaustive search found one, IEEE division
  * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */
@@ -208,6 +225,14 @@ int kvz_append_inplace(void* k_cache, void* v_cache,
                        int64_t k_head_stride, int64_t k_row_stride, int64_t v_head_stride, int64_t v_row_stride,
                        const int32_t* seg_start, const int32_t* base_len, int len_offset,
                        int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream);
+
+/* a10 before pruning (reference attention/kvcache.py:75-78: torch.cat along the sequence): append t rows per head to the DENSE
+ * cache in place.  k_cache / v_cache are [Hkv, capacity, D] with head stride cache_head_stride elements; the new rows go to
+ * rows fill .. fill+t of every head.  k_state / v_state as in kvz_append_inplace.  No device-resident metadata. */
+int kvz_dense_append(void* k_cache, void* v_cache, int64_t cache_head_stride, int fill,
+                     const void* k_state, const void* v_state,
+                     int64_t k_head_stride, int64_t k_row_stride, int64_t v_head_stride, int64_t v_row_stride,
+                     int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * a13  variable-length attention     reference call site: attention/attn.py:56-73

@@ -26,6 +26,11 @@ SIGNATURES = {
     "kvz_prof_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "kvz_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kvz_score_chunk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "kvz_async_create": (_i, [_i]),
+    "kvz_async_destroy": (_i, [_i]),
+    "kvz_async_wait": (_i, [_i, _i, _vp]),
+    "kvz_score_chunk_async": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz]),
+    "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

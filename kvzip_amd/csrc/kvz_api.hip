@@ -109,3 +109,97 @@ extern "C" int kvz_prof_read(const char* name, double* total_ms, int64_t* count)
     if (count) *count = 0;
     return KVZ_OK;
 }
+
+// ---- asynchronous scoring context ---------------------------------------------------------------------------------------
+// The scores of a layer are a side product of the scoring forward pass: nothing consumes them before prune().  The context
+// keeps, per slot (= layer), one "inputs ready" and one "scores done" event, so that a scoring call can be issued on a SIDE
+// stream and ordered against the caller's stream without any host-side event juggling:
+//     kvz_score_chunk_async:  record(ready[slot], caller); wait(side, ready[slot]); <kernels on side>; record(done[slot], side)
+//     kvz_async_wait:         wait(stream, done[slot])   (slot < 0: every pending slot)
+// Host objects only (events); no device memory.
+namespace kvz {
+struct AsyncCtx {
+    std::vector<hipEvent_t> ready, done;
+    std::vector<char> pending;
+};
+static std::mutex g_async_mu;
+static std::vector<AsyncCtx*> g_async;
+static AsyncCtx* async_get(int h) {
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    return (h >= 0 && h < (int)g_async.size()) ? g_async[h] : nullptr;
+}
+}  // namespace kvz
+
+extern "C" int kvz_async_create(int n_slots) {
+    KVZ_REQUIRE(n_slots > 0 && n_slots <= 65536, KVZ_EINVAL, "kvz_async_create: bad slot count %d", n_slots);
+    auto* c = new kvz::AsyncCtx();
+    c->ready.resize(n_slots);
+    c->done.resize(n_slots);
+    c->pending.assign(n_slots, 0);
+    for (int i = 0; i < n_slots; ++i) {
+        if (hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) != hipSuccess) {
+            kvz::set_error("kvz_async_create: hipEventCreate failed");
+            return KVZ_ELAUNCH;
+        }
+    }
+    std::lock_guard<std::mutex> lk(kvz::g_async_mu);
+    for (size_t i = 0; i < kvz::g_async.size(); ++i)
+        if (!kvz::g_async[i]) { kvz::g_async[i] = c; return (int)i; }
+    kvz::g_async.push_back(c);
+    return (int)kvz::g_async.size() - 1;
+}
+extern "C" int kvz_async_destroy(int handle) {
+    kvz::AsyncCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(kvz::g_async_mu);
+        if (handle < 0 || handle >= (int)kvz::g_async.size() || !kvz::g_async[handle]) return KVZ_OK;
+        c = kvz::g_async[handle];
+        kvz::g_async[handle] = nullptr;
+    }
+    for (auto e : c->ready) (void)hipEventDestroy(e);
+    for (auto e : c->done) (void)hipEventDestroy(e);
+    delete c;
+    return KVZ_OK;
+}
+extern "C" int kvz_async_wait(int handle, int slot, kvz_stream_t stream) {
+    kvz::AsyncCtx* c = kvz::async_get(handle);
+    KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_async_wait: bad handle %d", handle);
+    KVZ_REQUIRE(slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_async_wait: bad slot %d", slot);
+    const int lo = slot < 0 ? 0 : slot, hi = slot < 0 ? (int)c->pending.size() : slot + 1;
+    for (int i = lo; i < hi; ++i)
+        if (c->pending[i]) {
+            if (hipStreamWaitEvent((hipStream_t)stream, c->done[i], 0) != hipSuccess) {
+                kvz::set_error("kvz_async_wait: hipStreamWaitEvent failed");
+                return KVZ_ELAUNCH;
+            }
+            c->pending[i] = 0;
+        }
+    return KVZ_OK;
+}
+extern "C" int kvz_score_chunk_async(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
+                                     int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                                     int end, int q_len, int Hkv, int G, int D, int dtype, void* out, int64_t out_head_stride,
+                                     void* ws, size_t ws_bytes) {
+    kvz::AsyncCtx* c = kvz::async_get(handle);
+    KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_chunk_async: bad handle %d", handle);
+    KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_chunk_async: bad slot %d", slot);
+    if (side != caller) {
+        if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess) {
+            kvz::set_error("kvz_score_chunk_async: could not order the side stream behind the caller's stream");
+            return KVZ_ELAUNCH;
+        }
+    }
+    const int rc = kvz_score_chunk(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, out,
+                                   out_head_stride, ws, ws_bytes, side);
+    if (rc != KVZ_OK) return rc;
+    if (side != caller) {
+        if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {
+            kvz::set_error("kvz_score_chunk_async: hipEventRecord failed");
+            return KVZ_ELAUNCH;
+        }
+        c->pending[slot] = 1;
+    }
+    return KVZ_OK;
+}

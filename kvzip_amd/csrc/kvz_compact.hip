@@ -239,6 +239,30 @@ __global__ __launch_bounds__(256) void append_inplace_kernel(char* __restrict__ 
     }
 }
 
+// ---- append into the DENSE (pre-prune) cache: head h owns rows h*cache_head_rows .., the new rows go to row `fill` of every head.
+// No device-resident metadata (the slack-layout append reads seg_start / base_len from the device): one launch per layer and
+// chunk in the scoring loop, so the host side is a plain call with scalars.
+__global__ __launch_bounds__(256) void dense_append_kernel(char* __restrict__ kc, char* __restrict__ vc,
+                                                          const char* __restrict__ ks, const char* __restrict__ vs,
+                                                          int64_t cache_head_stride_bytes, int64_t k_head_stride_bytes,
+                                                          int64_t k_row_stride_bytes, int64_t v_head_stride_bytes,
+                                                          int64_t v_row_stride_bytes, int fill, int t, int row_bytes) {
+    const int h = blockIdx.y;
+    const int cpr = row_bytes / 16;
+    const int64_t chunks = (int64_t)t * cpr;
+    const char* k_src = ks + (int64_t)h * k_head_stride_bytes;
+    const char* v_src = vs + (int64_t)h * v_head_stride_bytes;
+    char* k_dst = kc + (int64_t)h * cache_head_stride_bytes + (int64_t)fill * row_bytes;
+    char* v_dst = vc + (int64_t)h * cache_head_stride_bytes + (int64_t)fill * row_bytes;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += stride) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i % cpr) * 16;
+        *reinterpret_cast<u32x4*>(k_dst + row * row_bytes + c) = *reinterpret_cast<const u32x4*>(k_src + row * k_row_stride_bytes + c);
+        *reinterpret_cast<u32x4*>(v_dst + row * row_bytes + c) = *reinterpret_cast<const u32x4*>(v_src + row * v_row_stride_bytes + c);
+    }
+}
+
 static int launch_gather(const CompactArgs& a, int layers, hipStream_t stream) {
     dim3 grid((unsigned)a.ntiles, (unsigned)a.Hkv, (unsigned)layers);
     dim3 block(CP_THREADS);
@@ -399,5 +423,31 @@ extern "C" int kvz_append_inplace(void* k_cache, void* v_cache, const void* k_st
                        k_head_stride * elem_bytes, k_row_stride * elem_bytes, v_head_stride * elem_bytes,
                        v_row_stride * elem_bytes, seg_start, base_len, len_offset, t, rb);
     KVZ_CHECK_LAUNCH("append_inplace_kernel");
+    return KVZ_OK;
+}
+
+extern "C" int kvz_dense_append(void* k_cache, void* v_cache, int64_t cache_head_stride, int fill, const void* k_state,
+                                const void* v_state, int64_t k_head_stride, int64_t k_row_stride, int64_t v_head_stride,
+                                int64_t v_row_stride, int Hkv, int t, int D, int elem_bytes, kvz_stream_t stream_) {
+    KVZ_REQUIRE(k_cache && v_cache && k_state && v_state, KVZ_EINVAL, "kvz_dense_append: null pointer");
+    KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && t > 0 && fill >= 0, KVZ_EINVAL, "kvz_dense_append: bad shape");
+    const int rb = D * elem_bytes;
+    KVZ_REQUIRE(rb > 0 && rb % 16 == 0, KVZ_EUNSUPPORTED, "kvz_dense_append: row bytes %d not a multiple of 16", rb);
+    KVZ_REQUIRE((int64_t)(fill + t) * D <= cache_head_stride, KVZ_EINVAL, "kvz_dense_append: rows %d..%d exceed the head capacity",
+                fill, fill + t);
+    KVZ_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(k_state) && aligned16(v_state), KVZ_EINVAL,
+                "kvz_dense_append: pointers must be 16-byte aligned");
+    KVZ_REQUIRE((cache_head_stride * elem_bytes) % 16 == 0 && (k_head_stride * elem_bytes) % 16 == 0 &&
+                    (k_row_stride * elem_bytes) % 16 == 0 && (v_head_stride * elem_bytes) % 16 == 0 &&
+                    (v_row_stride * elem_bytes) % 16 == 0,
+                KVZ_EINVAL, "kvz_dense_append: strides must be multiples of 16 bytes");
+    int64_t chunks = (int64_t)t * rb / 16;
+    int bx = (int)((chunks + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(dense_append_kernel, dim3(bx, Hkv), dim3(256), 0, (hipStream_t)stream_, reinterpret_cast<char*>(k_cache),
+                       reinterpret_cast<char*>(v_cache), reinterpret_cast<const char*>(k_state),
+                       reinterpret_cast<const char*>(v_state), cache_head_stride * elem_bytes, k_head_stride * elem_bytes,
+                       k_row_stride * elem_bytes, v_head_stride * elem_bytes, v_row_stride * elem_bytes, fill, t, rb);
+    KVZ_CHECK_LAUNCH("dense_append_kernel");
     return KVZ_OK;
 }

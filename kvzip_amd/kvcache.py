@@ -62,11 +62,13 @@ class _CacheBase(KVScore):
         self._store_v: List[torch.Tensor] = []
         self._fill: List[int] = []               # rows in use per layer
         self._reserve = int(reserve)
+        self._views = {}                         # (layer, rows) -> (key view, value view, storage) of the dense cache
 
     # -- dense (pre-prune) storage --------------------------------------------------------------
     def _dense_append(self, layer_idx: int, key_states: torch.Tensor, value_states: torch.Tensor):
         # the previous (asynchronous) scoring call of this layer read the rows that are about to be overwritten
-        self._wait_score(layer_idx)
+        if self._pending:
+            self._wait_score(layer_idx)
         t = key_states.shape[-2]
         if len(self._store_k) <= layer_idx:
             _, Hkv, _, D = key_states.shape
@@ -77,7 +79,8 @@ class _CacheBase(KVScore):
             self.key_cache.append(None)
             self.value_cache.append(None)
         f = self._fill[layer_idx]
-        cap = self._store_k[layer_idx].shape[2]
+        sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
+        cap = sk.shape[2]
         if f + t > cap:  # amortised growth
             new_cap = max(2 * cap, f + t + self._reserve)
             for store in (self._store_k, self._store_v):
@@ -85,19 +88,26 @@ class _CacheBase(KVScore):
                 new = torch.empty((1, old.shape[1], new_cap, old.shape[3]), dtype=old.dtype, device=old.device)
                 new[:, :, :f].copy_(old[:, :, :f])
                 store[layer_idx] = new
-        cap = self._store_k[layer_idx].shape[2]
+            sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
+            self._views.clear()
         if key_states.is_cuda and key_states.stride(-1) == 1 and value_states.stride(-1) == 1:
-            # one launch for K and V (strided sources accepted): rows f .. f+t of every head segment h*cap
-            seg, zero = self._dense_meta(cap, key_states.device)
-            D = key_states.shape[-1]
-            ops.append_inplace(self._store_k[layer_idx].view(-1, D), self._store_v[layer_idx].view(-1, D), key_states,
-                               value_states, seg, zero, f)
+            # one launch for K and V (strided sources accepted), scalars only: rows f .. f+t of every head
+            lib = ops._lib.load()
+            rc = lib.kvz_dense_append(sk.data_ptr(), sv.data_ptr(), sk.stride(1), f, key_states.data_ptr(), value_states.data_ptr(),
+                                      key_states.stride(1), key_states.stride(2), value_states.stride(1), value_states.stride(2),
+                                      sk.shape[1], t, sk.shape[3], sk.element_size(), ops._stream(sk))
+            ops.check(rc, "kvz_dense_append")
         else:
-            self._store_k[layer_idx][:, :, f:f + t].copy_(key_states)
-            self._store_v[layer_idx][:, :, f:f + t].copy_(value_states)
+            sk[:, :, f:f + t].copy_(key_states)
+            sv[:, :, f:f + t].copy_(value_states)
         self._fill[layer_idx] = f + t
-        self.key_cache[layer_idx] = self._store_k[layer_idx][:, :, :f + t]
-        self.value_cache[layer_idx] = self._store_v[layer_idx][:, :, :f + t]
+        # views of the filled part: the same lengths come back chunk after chunk (update ... slice), so they are cached
+        vw = self._views.get((layer_idx, f + t))
+        if vw is None or vw[2] is not sk:
+            vw = self._views[(layer_idx, f + t)] = (sk[:, :, :f + t], sv[:, :, :f + t], sk)
+            if len(self._views) > 16 * max(1, self.n_layers):
+                self._views.clear()
+        self.key_cache[layer_idx], self.value_cache[layer_idx] = vw[0], vw[1]
 
     def _dense_meta(self, cap: int, device):
         """(segment starts h*cap, zeros) int32 [Hkv] for the dense append launch, cached per capacity."""
@@ -112,6 +122,7 @@ class _CacheBase(KVScore):
         """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
         serving engine prefilled elsewhere); ``filled`` rows are in use."""
         self._wait_score()  # scoring calls still in flight read the storage that is being replaced
+        self._views.clear()
         self._store_k, self._store_v = list(store_k), list(store_v)
         self._fill = [filled for _ in store_k]
         self.key_cache = [k[:, :, :filled] for k in self._store_k]
@@ -131,6 +142,7 @@ class _CacheBase(KVScore):
             self._wait_score()
         except Exception:
             pass
+        self._release_async()
 
     # reference: kvcache.py:108-112
     def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
@@ -267,6 +279,7 @@ class EvictCache(_CacheBase):
         ks, vs = ops.compact_layers(self.key_cache, self.value_cache, plan, totals)
         self.key_cache, self.value_cache = list(ks), list(vs)
         self._store_k, self._store_v, self._fill = [], [], []  # release the dense storage
+        self._views.clear()
         self._plan = plan
         cu_head = torch.arange(Hkv + 1, dtype=torch.int32, device=self.device)
         self.info = {

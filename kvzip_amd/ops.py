@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import KVZ_BF16, KVZ_F16, KvzError, check
+from ._lib import KVZ_BF16, KVZ_F16, KvzError, check  # noqa: F401
 
 COMPACT_TILE = 1024
 

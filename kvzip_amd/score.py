@@ -88,25 +88,31 @@ class KVScore:
         self.device = None
         self.get_score = True
         self.causal_mask_score = None  # kept for interface compatibility; the mask is applied inside the kernel
-        self._score = None
+        self._score = None             # externally assigned scores (list / tensor); None = views of the score buffer
         self.sink = None
         self.start_idx, self.end_idx = None, None
         self.ctx_len = None
         self._score_buf: Optional[torch.Tensor] = None
         self._score_fill: List[int] = []
         self._score_ws: List[Optional[torch.Tensor]] = []
+        self._ws_need = {}             # (q_len, m, H) -> workspace bytes
         self.n_score_streams = 2       # 1 = score on the caller's stream
         self._score_exclusive = False  # True: the next calls run alone on the caller's stream (clean kernel timings)
         self._score_side: List["torch.cuda.Stream"] = []
-        self._score_events = {}        # layer -> event recorded after its latest scoring call
-        self._score_ev_pool = {}       # layer -> reusable event object
+        self._async = -1               # handle of the library's asynchronous-scoring context (events per layer)
+        self._pending = False          # scoring calls may still be in flight on a side stream
 
     # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
     @property
     def score(self):
-        """Per-layer scores (reference attribute).  Reading it orders the caller's stream behind outstanding scoring."""
+        """Per-layer scores (reference attribute: list of L ``[1, Hkv, n]`` tensors, or whatever was assigned).  Reading it
+        orders the caller's stream behind outstanding scoring."""
         self._wait_score()
-        return self._score
+        if self._score is not None:
+            return self._score
+        if self._score_buf is None:
+            return None
+        return [self._score_buf[l][:, :, :self._score_fill[l]] for l in range(self.n_layers)]
 
     @score.setter
     def score(self, value):
@@ -114,27 +120,31 @@ class KVScore:
 
     def _wait_score(self, layer_idx: Optional[int] = None):
         """Make the current stream wait for the scoring calls still in flight (of one layer, or of all)."""
-        if not self._score_events:
+        if not self._pending or self._async < 0:
             return
-        cur = torch.cuda.current_stream()
+        lib = ops._lib.load()
+        ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx,
+                                     torch.cuda.current_stream(self.device).cuda_stream), "kvz_async_wait")
         if layer_idx is None:
-            for ev in self._score_events.values():
-                cur.wait_event(ev)
-            self._score_events = {}
-        else:
-            ev = self._score_events.pop(layer_idx, None)
-            if ev is not None:
-                cur.wait_event(ev)
+            self._pending = False
+
+    def _release_async(self):
+        if self._async >= 0:
+            try:
+                ops._lib.load().kvz_async_destroy(self._async)
+            except Exception:
+                pass
+            self._async = -1
 
     # reference: attention/score.py:25-31
     def init_score(self):
         self.get_score = True
         self.causal_mask_score = None
         n = int(self.ctx_len) if self.ctx_len is not None else 0
-        self._score_buf = torch.empty((self.n_layers, 1, self.n_heads_kv, n), dtype=self.dtype, device=self.device)
         self._wait_score()
+        self._score_buf = torch.empty((self.n_layers, 1, self.n_heads_kv, n), dtype=self.dtype, device=self.device)
         self._score_fill = [0 for _ in range(self.n_layers)]
-        self._score = [self._score_buf[l][:, :, :0] for l in range(self.n_layers)]
+        self._score = None
 
     # reference: attention/score.py:33-34
     def _update_score(self, layer_idx: int, score: torch.Tensor):
@@ -145,7 +155,6 @@ class KVScore:
         self._wait_score(layer_idx)
         self._score_buf[layer_idx][:, :, f:f + m].copy_(score)
         self._score_fill[layer_idx] = f + m
-        self._score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
 
     def _ensure_score_capacity(self, need: int):
         if self._score_buf.shape[-1] >= need:
@@ -156,44 +165,63 @@ class KVScore:
         if old:
             new[..., :old].copy_(self._score_buf)
         self._score_buf = new
-        self._score = [new[l][:, :, :self._score_fill[l]] for l in range(self.n_layers)]
 
     # reference: attention/score.py:36-65
     def _get_score(self, query_states: torch.Tensor, key_states: torch.Tensor, layer_idx: int):
         """query ``[1, H, q, D]``, key ``[1, Hkv, klen, D]`` (cache ++ repeat chunk).  Writes the chunk's
-        ``[1, Hkv, end_idx-start_idx]`` scores straight into the layer's score buffer."""
+        ``[1, Hkv, end_idx-start_idx]`` scores straight into the layer's score buffer.  ONE call into the library: the
+        side-stream ordering (events) lives behind ``kvz_score_chunk_async``."""
+        lib = ops._lib.load()
         m = self.end_idx - self.start_idx
         f = self._score_fill[layer_idx]
-        self._ensure_score_capacity(f + m)
-        out = self._score_buf[layer_idx][:, :, f:f + m]
+        if self._score_buf.shape[-1] < f + m:
+            self._ensure_score_capacity(f + m)
+        buf = self._score_buf
         bsz, H, q_len, D = query_states.shape
-        need = ops._lib.load().kvz_score_workspace_bytes(self.n_heads_kv, H // self.n_heads_kv, q_len, m, self.sink)
-        nstreams = 1 if (self._score_exclusive or not query_states.is_cuda) else max(1, int(self.n_score_streams))
+        Hkv = self.n_heads_kv
+        klen = key_states.shape[2]
+        if not query_states.is_cuda:
+            raise ops.KvzError("the HIP path needs device tensors (no CPU fallback)")
+        assert bsz == 1 and query_states.stride(3) == 1 and query_states.stride(2) == D
+        assert key_states.stride(3) == 1 and key_states.stride(2) == D and key_states.dtype == query_states.dtype
+        dev = query_states.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        need = self._ws_need.get((q_len, m, H))
+        if need is None:
+            need = self._ws_need[(q_len, m, H)] = lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, self.sink)
+        nstreams = 1 if self._score_exclusive else max(1, int(self.n_score_streams))
         slot = layer_idx % nstreams if nstreams > 1 else 0
         while len(self._score_ws) <= slot:
             self._score_ws.append(None)
-        if self._score_ws[slot] is None or self._score_ws[slot].numel() < need:
+        ws = self._score_ws[slot]
+        if ws is None or ws.numel() < need:
             self._wait_score()  # (the old workspace of this slot may still be in use)
-            self._score_ws[slot] = torch.empty(need, dtype=torch.uint8, device=query_states.device)
+            ws = self._score_ws[slot] = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self._async < 0:
+            self._async = lib.kvz_async_create(self.n_layers)
+            if self._async < 0:
+                ops.check(self._async, "kvz_async_create")
+        cur = torch.cuda.current_stream(dev).cuda_stream
         if nstreams == 1:
             self._wait_score()  # the caller's stream: everything before it is ordered anyway, later calls wait for it
-            ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,
-                            workspace=self._score_ws[0])
+            side = cur
         else:
-            self._score_side = _side_streams(query_states.device, nstreams)
-            side, cur = self._score_side[slot], torch.cuda.current_stream(query_states.device)
-            side.wait_stream(cur)                # the inputs (and this layer's cache update) were produced there
-            query_states.record_stream(side)     # a temporary of the forward pass must outlive the side stream's use
+            if len(self._score_side) < nstreams:
+                self._score_side = _side_streams(dev, nstreams)
+            st = self._score_side[slot]
+            side = st.cuda_stream
+            query_states.record_stream(st)  # a temporary of the forward pass must outlive the side stream's use
             # (key_states is a view of the cache storage, which is only reallocated after _wait_score)
-            ops.score_chunk(query_states, key_states, self.sink, self.start_idx, self.end_idx, out=out,
-                            workspace=self._score_ws[slot], stream=side)
-            ev = self._score_ev_pool.get(layer_idx)
-            if ev is None:
-                ev = self._score_ev_pool[layer_idx] = torch.cuda.Event()
-            ev.record(side)
-            self._score_events[layer_idx] = ev
+            self._pending = True
+        n_tot = buf.shape[-1]
+        out_ptr = buf.data_ptr() + (layer_idx * Hkv * n_tot + f) * buf.element_size()
+        rc = lib.kvz_score_chunk_async(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
+                                       key_states.data_ptr(), key_states.stride(1), klen, self.sink, self.start_idx,
+                                       self.end_idx, q_len, Hkv, H // Hkv, D, ops._dtype_code(query_states.dtype), out_ptr, n_tot,
+                                       ws.data_ptr(), ws.numel())
+        ops.check(rc, "kvz_score_chunk_async")
         self._score_fill[layer_idx] = f + m
-        self._score[layer_idx] = self._score_buf[layer_idx][:, :, :f + m]
 
     # ------------------------------------------------------------------------------------------
     def _stacked_score(self, score) -> torch.Tensor:
