@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KVZ_ABI_VERSION 1
+#define KVZ_ABI_VERSION 2
 
 /* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
 #define KVZ_F16 0
@@ -246,14 +246,18 @@ int kvz_dense_append(void* k_cache, void* v_cache, int64_t cache_head_stride, in
  *   P = softmax(q.k^T * scale) in fp32, out = P.v rounded to half
  * ------------------------------------------------------------------------- */
 size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k);
+/* k_meta_host (optional, HOST pointer, may be NULL): [k_start[0..Hkv), k_len[0..Hkv)] as the caller knows them on the host (the
+ * cache object does: one D2H copy per prune).  With it the kernel gets the head segments as launch arguments and does not start
+ * with a dependent load of the device arrays.  Up to 64 heads; ignored beyond.
+ * ws: kvz_varlen_attn_workspace_bytes(...) bytes, ZERO-FILLED when first used (arrival counters; every call leaves them zero). */
 int kvz_varlen_attn(const void* q, const void* k, const void* v,
-                    const int32_t* k_start, const int32_t* k_len, int k_len_offset,
+                    const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
                     int Hkv, int G, int q_len, int D, int max_len_k,
                     float scale, int causal, int dtype,
                     void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
 
 /* a10 + a13 fused (decode step, one new token):  kvz_append_inplace(t = 1) followed by kvz_varlen_attn(q_len = 1) in ONE
- * launch of the split kernel (+ the combine kernel).  Replaces the pair
+ * launch.  Replaces the pair
  *   past_key_value.update(...)   reference attention/attn.py:44-48  -> csrc/csrc/cuda_api.cu:68-111
  *   flash_attn_varlen_func(...)  reference attention/attn.py:61-71
  * for the generation loop.  k_state / v_state: [Hkv, 1, D] views (head stride in elements, D contiguous).  The row is
@@ -263,7 +267,7 @@ int kvz_varlen_attn(const void* q, const void* k, const void* v,
 int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache,
                            const void* k_state, const void* v_state,
                            int64_t k_state_head_stride, int64_t v_state_head_stride,
-                           const int32_t* k_start, const int32_t* k_len, int k_len_offset,
+                           const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
                            int Hkv, int G, int D, int max_len_k, float scale, int dtype,
                            void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
 

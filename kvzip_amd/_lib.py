@@ -46,9 +46,9 @@ SIGNATURES = {
     "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
-    "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz,
-                                    _vp]),
+    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp,
+                                    _sz, _vp]),
 }
 
 _lib = None
@@ -73,8 +73,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.kvz_abi_version() != 1:
-        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding 1")
+    if lib.kvz_abi_version() != 2:
+        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding 2")
     _lib = lib
     return lib
 

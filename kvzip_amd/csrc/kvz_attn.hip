@@ -5,13 +5,13 @@
 // are MQA heads, causal mask bottom-right aligned.
 //
 // Decode (q_len = 1) is HBM-bound: every kept K and V row is read exactly once per generated token.
-// Design: split-K "flash decoding".
-//   grid = (splits, Hkv, row tiles of 16 query rows); a block owns one key chunk of one head, its 8
-//   waves stride over 32-key tiles of the chunk.
+// Design: split-K "flash decoding" in ONE launch.
+//   grid = (work items, row tiles of 16 query rows); a block owns one key range of one head (ranges are cut from the SUM of
+//   the ragged head lengths), its 8 waves stride over 32-key tiles of the range.
 //   S^T = K.Q^T on v_mfma_f32_16x16x32 with K rows loaded straight from HBM as the A operand (16-byte
 //   contiguous per lane, no LDS); softmax state lives in registers (lane = one query row);
 //   O^T += V^T.P^T with V staged through a per-wave padded LDS tile and read back transposed by
-//   ds_read_b64_tr_b16.  A second small kernel merges the per-split partials.
+//   ds_read_b64_tr_b16.  The last block of a head to finish merges the head's partials.
 #include "kvz_common.h"
 
 #include <stdlib.h>
@@ -50,21 +50,53 @@ template <int D> struct AttnCfg {
     static constexpr int VLOADS = AT_KT * CPR / WAVE;       // 16-byte V loads per lane per tile
 };
 
-// APPEND: the decode step's O(1) cache append is done by this kernel.  k_len_offset already counts the new token; the
-// block(s) that own the last key range of a head first copy the new K and V row of that head from the state tensors into
-// the cache (row k_start[h] + len - 1) and then read it back like any other key (no other block touches that row).
-template <typename T, int D, bool APPEND>
-__global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
-    const T* __restrict__ q, const T* k, const T* v, const int32_t* __restrict__ k_start,
-    const int32_t* __restrict__ k_len, int k_len_offset, int G, int q_len, int chunk, float scale, int causal,
-    float* __restrict__ part_o, float* __restrict__ part_ml, int n_splits, int n_rtiles,
-    const T* __restrict__ k_new, const T* __restrict__ v_new, int64_t kn_head_stride, int64_t vn_head_stride) {
+// APPEND: the decode step's O(1) cache append is done by the attention kernel.  k_len_offset already counts the new token; the
+// block that owns the last key range of a head first copies the new K and V row of that head from the state tensors into
+// the cache (row k_start[h] + len - 1) and then reads it back like any other key (no other block touches that row).
+
+// ---- round 2: ragged-aware work items -------------------------------------------------------------------------------------
+// Work items are cut from the SUM of the head lengths (a head of 120 k keys gets 30 x the items of a head of 4 k keys; a
+// dropped head of a head-level cache gets one), not from Hkv x the longest head: every block derives its (head, key range)
+// from the lengths (kernel arguments when the host knows them, else scalar loads).  The partials of a head are merged by a
+// second, split-parallel kernel.  (Merging them inside this kernel - last block of a head to arrive, write-through partials,
+// one device-scope counter, one acquire fence - was built and measured in round 2: correct, but the chain store drain ->
+// atomic -> fence -> two dependent rounds of reads costs 10-12 us of serial tail against 5.4 + 2 us for the separate launch;
+// see profiles/r2_attn_fused_vs_split.txt.)
+constexpr int AT_MAXH = 64;
+struct HeadMeta { int32_t start[AT_MAXH]; int32_t len[AT_MAXH]; };
+
+template <typename T, int D, bool APPEND, bool HOSTMETA>
+__global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
+    const T* __restrict__ q, const T* k, const T* v, const int32_t* __restrict__ k_start, const int32_t* __restrict__ k_len,
+    int k_len_offset, HeadMeta hm, int Hkv, int G, int q_len, int target_items, float scale, int causal, float* part_o,
+    float* part_ml, uint32_t* counters, int n_rtiles, T* __restrict__ out, const T* __restrict__ k_new,
+    const T* __restrict__ v_new, int64_t kn_head_stride, int64_t vn_head_stride) {
     typedef AttnCfg<D> C;
     typedef typename HalfTraits<T>::v8 v8;
-    const int split = blockIdx.x, h = blockIdx.y, rt = blockIdx.z;
-    const int len = k_len[h] + k_len_offset;
+    auto len_of = [&](int hh) -> int { return (HOSTMETA ? hm.len[hh] : k_len[hh]) + k_len_offset; };
+    // ---- this block's work item: (head, key range) from the ragged lengths (all wave-uniform scalar work) ----
+    int total = 0;
+    for (int hh = 0; hh < Hkv; ++hh) total += len_of(hh);
+    int chunk = (total + target_items - 1) / target_items;
+    chunk = (chunk + 127) / 128 * 128;
+    if (chunk < 128) chunk = 128;
+    int h = -1, split = 0, nsp = 0, first_item = 0;
+    {
+        int b = blockIdx.x, items = 0;
+        for (int hh = 0; hh < Hkv; ++hh) {
+            const int n = max(1, (len_of(hh) + chunk - 1) / chunk);  // (an empty head still gets one item: it writes zeros)
+            if (h < 0) {
+                if (b < n) { h = hh; split = b; nsp = n; first_item = items; }
+                else b -= n;
+            }
+            items += n;
+        }
+    }
+    if (h < 0) return;  // beyond the last item
+    const int rt = blockIdx.y;
+    const int len = len_of(h);
+    const int64_t seg = HOSTMETA ? hm.start[h] : k_start[h];
     const int c0 = split * chunk;
-    if (c0 >= len) return;
     const int c1 = min(len, c0 + chunk);
     if (APPEND && c1 == len) {
         constexpr int CH = D * 2 / 16;  // 16-byte chunks per row
@@ -72,7 +104,7 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
             const bool is_v = (int)threadIdx.x >= CH;
             const int c = (int)threadIdx.x - (is_v ? CH : 0);
             const char* src = reinterpret_cast<const char*>(is_v ? v_new + h * vn_head_stride : k_new + h * kn_head_stride) + c * 16;
-            char* dst = const_cast<char*>(reinterpret_cast<const char*>(is_v ? v : k)) + ((int64_t)k_start[h] + len - 1) * (D * 2) + c * 16;
+            char* dst = const_cast<char*>(reinterpret_cast<const char*>(is_v ? v : k)) + (seg + len - 1) * (D * 2) + c * 16;
             *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
         }
         __syncthreads();  // (workgroup-scope release/acquire: the row is visible to the loads of this block below)
@@ -98,21 +130,18 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
             qf[kk] = __builtin_bit_cast(v8, raw);
         }
     }
-    // last visible key index for this lane's query row (bottom-right aligned causal mask)
-    int limit = causal ? (qrow / G) + len - q_len : len - 1;
+    int limit = causal ? (qrow / G) + len - q_len : len - 1;  // last visible key of this lane's query row (bottom-right aligned)
     if (!qvalid) limit = -1;
 
-    const char* kbase = reinterpret_cast<const char*>(k) + (int64_t)k_start[h] * C::ROW_BYTES;
-    const char* vbase = reinterpret_cast<const char*>(v) + (int64_t)k_start[h] * C::ROW_BYTES;
+    const char* kbase = reinterpret_cast<const char*>(k) + seg * C::ROW_BYTES;
+    const char* vbase = reinterpret_cast<const char*>(v) + seg * C::ROW_BYTES;
 
     float m_run = -INFINITY, l_run = 0.f;
     f4 o[C::DB];
 #pragma unroll
     for (int i = 0; i < C::DB; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
-
     const float sl2 = scale * 1.44269504088896340736f;  // work in the exp2 domain
 
-    // HBM loads of one 32-key tile: K rows (MFMA A operands, 16 B per lane) and V rows (to be staged through LDS)
     auto load_tile = [&](u32x4 (&kr)[2][C::KK], u32x4 (&vr)[C::VLOADS], int t0) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -130,7 +159,6 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
             vr[it] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * C::ROW_BYTES + (c % C::CPR) * 16);
         }
     };
-    // register double buffering: the next tile's 16 KiB are in flight while the current tile is computed
     u32x4 kraw[2][C::KK], vraw[C::VLOADS], knext[2][C::KK], vnext[C::VLOADS];
     {
         const int tfirst = c0 + wave * AT_KT;
@@ -140,7 +168,6 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     for (int t0 = c0 + wave * AT_KT; t0 < c1; t0 += AT_WAVES * AT_KT) {
         const int tn = t0 + AT_WAVES * AT_KT;
         if (tn < c1) load_tile(knext, vnext, tn);
-        // ---- S^T = K.Q^T : rows = keys (quad*4+reg within each 16-key sub tile), col = query row ----
         f4 s[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -149,13 +176,11 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
             for (int kk = 0; kk < C::KK; ++kk)
                 s[sub] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, kraw[sub][kk]), qf[kk], s[sub]);
         }
-        // ---- stage V into the padded per-wave LDS tile -------------------------------------------
 #pragma unroll
         for (int it = 0; it < C::VLOADS; ++it) {
             const int c = it * WAVE + lane;
             *reinterpret_cast<u32x4*>(wl + (c / C::CPR) * C::VSTRIDE + (c % C::CPR) * 16) = vraw[it];
         }
-        // ---- online softmax (exp2 domain), one query row per lane ------------------------------------
         float sv[8];
         float tmax = -INFINITY;
 #pragma unroll
@@ -185,16 +210,11 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
         for (int i = 0; i < C::DB; ++i) {
             o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
         }
-        // ---- O^T += V^T.P^T : A = V^T (transposed LDS reads), B = P^T (already in registers) ----------
-        // lane t of a 16-lane group supplies the address of 4 consecutive halfs of row (t>>2), cols (t&3)*4..+3
-        // of a 4(key) x 16(d) block; after the hardware transpose lane c holds column c = 4 keys of one d.
         const char* trp = wl + (quad * 4 + (l15 >> 2)) * C::VSTRIDE + (l15 & 3) * 8;
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-            s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s4*)(trp + db * 32));
-            s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s4*)(trp + 16 * C::VSTRIDE + db * 32));
+            s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(trp + db * 32));
+            s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(trp + 16 * C::VSTRIDE + db * 32));
             s8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             o[db] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, both), pb, o[db]);
         }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
         }
     }
 
-    // ---- merge the 4 waves of the block through LDS (each wave writes only its own region) ----------
+    // ---- merge the 8 waves of the block through LDS (each wave writes only its own region) ----------
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     float* wo = reinterpret_cast<float*>(wl);            // [16 q][D]
@@ -220,49 +240,54 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split_kernel(
     if (quad == 0) { wm[l15] = m_run; wm[16 + l15] = l_run; }
     __syncthreads();
 
-    const int64_t pbase = (((int64_t)h * n_rtiles + rt) * n_splits + split) * AT_RT;
     const int rows_valid = min(AT_RT, R - rt * AT_RT);
-    for (int e = threadIdx.x; e < rows_valid * D; e += AT_THREADS) {
-        const int qq = e / D, d = e % D;
+    const int64_t pbase = ((int64_t)(first_item + split) * n_rtiles + rt) * AT_RT;  // partial slot of this item
+    for (int e = threadIdx.x; e < rows_valid * (D / 2); e += AT_THREADS) {
+        const int qq = e / (D / 2), d = (e % (D / 2)) * 2;
         float mw[AT_WAVES], M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < AT_WAVES; ++w) {
             mw[w] = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[AT_RT * D + qq];
             M = fmaxf(M, mw[w]);
         }
-        float acc = 0.f, lsum = 0.f;
+        float a0 = 0.f, a1 = 0.f, lsum = 0.f;
 #pragma unroll
         for (int w = 0; w < AT_WAVES; ++w) {
             const float* pw = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS);
             const float wgt = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - M);
-            acc += wgt * pw[qq * D + d];
+            a0 += wgt * pw[qq * D + d];
+            a1 += wgt * pw[qq * D + d + 1];
             lsum += wgt * pw[AT_RT * D + 16 + qq];
         }
-        part_o[(pbase + qq) * D + d] = acc;
-        if (d == 0) {
-            part_ml[(pbase + qq) * 2] = M;
-            part_ml[(pbase + qq) * 2 + 1] = lsum;
-        }
+        *reinterpret_cast<float2*>(part_o + (pbase + qq) * D + d) = make_float2(a0, a1);
+        if (d == 0) *reinterpret_cast<float2*>(part_ml + (pbase + qq) * 2) = make_float2(M, lsum);
     }
 }
 
-// merge the per-split partials.  grid = (Hkv, row tiles, 16 query rows); block = 1024 threads = (1024/D) split
-// slices x D columns.  Every load of the main loop is independent (split-parallel): throughput-, not latency-bound.
+// merge the partials of the key ranges.  grid = (Hkv, row tiles, 16 query rows); block = 1024 threads = (1024/D) slices of the
+// partials x D columns.  Every load of the main loop is independent (split-parallel): throughput-, not latency-bound.
 constexpr int CB_THREADS = 1024;
-template <typename T, int D>
-__global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const float* __restrict__ part_o,
-                                                                        const float* __restrict__ part_ml,
-                                                                        const int32_t* __restrict__ k_len,
-                                                                        int k_len_offset, int G,
-                                                                        int q_len, int chunk, int n_splits,
-                                                                        int n_rtiles, T* __restrict__ out) {
+template <typename T, int D, bool HOSTMETA>
+__global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine2_kernel(const float* __restrict__ part_o,
+                                                                         const float* __restrict__ part_ml,
+                                                                         const int32_t* __restrict__ k_len, int k_len_offset,
+                                                                         HeadMeta hm, int Hkv, int G, int q_len, int target_items,
+                                                                         int n_rtiles, T* __restrict__ out) {
     constexpr int SLICES = CB_THREADS / D;
     const int h = blockIdx.x, rt = blockIdx.y, qq = blockIdx.z;
     const int R = q_len * G;
     if (rt * AT_RT + qq >= R) return;
-    const int len = k_len[h] + k_len_offset;
-    const int nsp = (len + chunk - 1) / chunk;
-    const int64_t base = (((int64_t)h * n_rtiles + rt) * n_splits) * AT_RT + qq;  // + s * AT_RT
+    auto len_of = [&](int hh) -> int { return (HOSTMETA ? hm.len[hh] : k_len[hh]) + k_len_offset; };
+    int total = 0;
+    for (int hh = 0; hh < Hkv; ++hh) total += len_of(hh);
+    int chunk = (total + target_items - 1) / target_items;
+    chunk = (chunk + 127) / 128 * 128;
+    if (chunk < 128) chunk = 128;
+    int first_item = 0;
+    for (int hh = 0; hh < h; ++hh) first_item += max(1, (len_of(hh) + chunk - 1) / chunk);
+    const int nsp = max(1, (len_of(h) + chunk - 1) / chunk);
+    const int64_t base = ((int64_t)first_item * n_rtiles + rt) * AT_RT + qq;  // + s * n_rtiles * AT_RT
+    const int64_t istride = (int64_t)n_rtiles * AT_RT;
     const int tid = threadIdx.x;
     const int d = tid % D, slice = tid / D;
 
@@ -270,9 +295,51 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const f
     __shared__ float s_acc[SLICES][D];
     __shared__ float s_M, s_L;
 
-    // global maximum of the row over all splits
+    constexpr int PER = 8;  // partials per thread on the fast path
+    if (nsp <= PER * SLICES) {
+        // ONE round trip to memory: every thread issues the loads of its (up to 8) partials - statistics and its column -
+        // before anything depends on them; the row maximum and the denominator are then block reductions over registers.
+        float2 ml[PER];
+        float ov[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s2 = slice + i * SLICES;
+            const int64_t pi = base + (int64_t)min(s2, nsp - 1) * istride;
+            ml[i] = *reinterpret_cast<const float2*>(part_ml + pi * 2);
+            ov[i] = part_o[pi * D + d];
+            if (s2 >= nsp) ml[i] = make_float2(-INFINITY, 0.f);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) mx = fmaxf(mx, ml[i].x);
+        mx = wave_reduce_max(mx);
+        if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+        __syncthreads();
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < CB_THREADS / WAVE; ++w) M = fmaxf(M, s_red[w]);
+        float acc = 0.f, lp = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const float wgt = (ml[i].x == -INFINITY) ? 0.f : exp2f(ml[i].x - M);
+            acc += wgt * ov[i];
+            lp += wgt * ml[i].y;
+        }
+        s_acc[slice][d] = acc;
+        __syncthreads();  // (also: everybody has read s_red)
+        if (d == 0) s_red[slice] = lp;  // one thread per slice holds that slice's share of the denominator
+        __syncthreads();
+        if (tid < D) {
+            float a = 0.f, l = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < SLICES; ++sl) { a += s_acc[sl][tid]; l += s_red[sl]; }
+            out[((int64_t)h * R + rt * AT_RT + qq) * D + tid] = (T)((l > 0.f) ? a / l : 0.f);
+        }
+        return;
+    }
+    // general path (more partials than the fast path holds in registers): three dependent passes
     float mx = -INFINITY;
-    for (int s = tid; s < nsp; s += CB_THREADS) mx = fmaxf(mx, part_ml[(base + (int64_t)s * AT_RT) * 2]);
+    for (int s2 = tid; s2 < nsp; s2 += CB_THREADS) mx = fmaxf(mx, part_ml[(base + s2 * istride) * 2]);
     mx = wave_reduce_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
@@ -284,10 +351,9 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const f
     }
     __syncthreads();
     const float M = s_M;
-    // denominator
     float lp = 0.f;
-    for (int s = tid; s < nsp; s += CB_THREADS) {
-        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (base + (int64_t)s * AT_RT) * 2);
+    for (int s2 = tid; s2 < nsp; s2 += CB_THREADS) {
+        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (base + s2 * istride) * 2);
         lp += (ml.x == -INFINITY) ? 0.f : exp2f(ml.x - M) * ml.y;
     }
 #pragma unroll
@@ -301,10 +367,9 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine_kernel(const f
         for (int w = 0; w < CB_THREADS / WAVE; ++w) l2 += s_red[w];
         s_L = l2;
     }
-    // numerator: this thread's column over its slice of the splits
     float acc = 0.f;
-    for (int s = slice; s < nsp; s += SLICES) {
-        const int64_t pi = base + (int64_t)s * AT_RT;
+    for (int s2 = slice; s2 < nsp; s2 += SLICES) {
+        const int64_t pi = base + s2 * istride;
         const float ms = part_ml[pi * 2];
         const float wgt = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
         acc += wgt * part_o[pi * D + d];
@@ -324,48 +389,58 @@ static inline int attn_items() {
     static int items = 0;
     if (!items) {
         const char* e = getenv("KVZ_ATTN_ITEMS");  // tuning knob (work items the key ranges are cut into)
-        items = e ? atoi(e) : 256;
-        if (items < 1) items = 256;
+        items = e ? atoi(e) : 192;  // 128 / 192 / 256 / 384 measured in round 2 (profiles/r2_attn_items.txt): 192 is best or within
+        if (items < 1) items = 192;  // 1 % of the best on uniform, AdaKV-ragged and head-level caches
     }
     return items;
 }
-static inline int attn_chunk(int Hkv, int max_len_k) {
-    // aim for ~256 (head, chunk) work items = one per CU; chunk is a multiple of one block-iteration (128 keys).  The kernel
-    // is latency-bound per block (Q fragments, first tile), so fewer and longer key streams win over a second resident
-    // block per CU: 256 -> 1066 tokens/s, 512 -> 984, 1024 -> 919 on the headline cache (ragged heads leave fewer items
-    // than the target anyway).
-    const int items = attn_items();
-    int64_t c = ((int64_t)Hkv * max_len_k + items - 1) / items;
-    c = (c + 127) / 128 * 128;
-    if (c < 128) c = 128;
-    return (int)c;
+static inline size_t align256a(size_t x) { return (x + 255) & ~(size_t)255; }
+struct AttnWs { uint32_t* counters; float* part_ml; float* part_o; size_t bytes; };
+static inline AttnWs attn_ws(void* ws, int Hkv, int n_rtiles, int D) {
+    const size_t items = (size_t)attn_items() + Hkv;
+    AttnWs w;
+    char* p = reinterpret_cast<char*>(ws);
+    w.counters = reinterpret_cast<uint32_t*>(p);
+    p += align256a((size_t)Hkv * n_rtiles * sizeof(uint32_t));
+    w.part_ml = reinterpret_cast<float*>(p);
+    p += align256a(items * n_rtiles * AT_RT * 2 * sizeof(float));
+    w.part_o = reinterpret_cast<float*>(p);
+    p += align256a(items * n_rtiles * AT_RT * D * sizeof(float));
+    w.bytes = (size_t)(p - reinterpret_cast<char*>(ws));
+    return w;
 }
 
 template <typename T, int D>
 static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len,
-                       int k_len_offset, int Hkv, int G, int q_len, int max_len_k, float scale, int causal, void* out, void* ws,
-                       hipStream_t stream, const void* k_new = nullptr, const void* v_new = nullptr, int64_t kn_stride = 0,
-                       int64_t vn_stride = 0) {
-    const int chunk = attn_chunk(Hkv, max_len_k);
-    const int n_splits = (max_len_k + chunk - 1) / chunk > 0 ? (max_len_k + chunk - 1) / chunk : 1;
+                       int k_len_offset, const int32_t* meta_host, int Hkv, int G, int q_len, float scale, int causal, void* out,
+                       void* ws, hipStream_t stream, const void* k_new = nullptr, const void* v_new = nullptr,
+                       int64_t kn_stride = 0, int64_t vn_stride = 0) {
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
-    float* part_o = reinterpret_cast<float*>(ws);
-    float* part_ml = part_o + (size_t)Hkv * n_rtiles * n_splits * AT_RT * D;
-    ProfScope ps("varlen_attn", stream);  // split + combine
-    if (k_new)
-        hipLaunchKernelGGL((varlen_attn_split_kernel<T, D, true>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
-                           reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
-                           k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles,
-                           reinterpret_cast<const T*>(k_new), reinterpret_cast<const T*>(v_new), kn_stride, vn_stride);
+    const AttnWs w = attn_ws(ws, Hkv, n_rtiles, D);
+    const int target = attn_items();
+    HeadMeta hm;
+    const bool host = meta_host != nullptr && Hkv <= AT_MAXH;
+    if (host)
+        for (int h = 0; h < Hkv; ++h) { hm.start[h] = meta_host[h]; hm.len[h] = meta_host[Hkv + h]; }
+    const dim3 grid(target + Hkv, n_rtiles), block(AT_THREADS);
+    ProfScope ps("varlen_attn", stream);
+#define KVZ_ATTN_LAUNCH(APP, HOST)                                                                                                \
+    hipLaunchKernelGGL((varlen_attn_split2_kernel<T, D, APP, HOST>), grid, block, 0, stream, reinterpret_cast<const T*>(q),          \
+                       reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v), k_start, k_len, k_len_offset, hm, Hkv, G,     \
+                       q_len, target, scale, causal, w.part_o, w.part_ml, w.counters, n_rtiles, reinterpret_cast<T*>(out),          \
+                       reinterpret_cast<const T*>(k_new), reinterpret_cast<const T*>(v_new), kn_stride, vn_stride)
+    if (k_new) { if (host) KVZ_ATTN_LAUNCH(true, true); else KVZ_ATTN_LAUNCH(true, false); }
+    else { if (host) KVZ_ATTN_LAUNCH(false, true); else KVZ_ATTN_LAUNCH(false, false); }
+#undef KVZ_ATTN_LAUNCH
+    KVZ_CHECK_LAUNCH("varlen_attn_split2_kernel");
+    const dim3 cgrid(Hkv, n_rtiles, AT_RT), cblock(CB_THREADS);
+    if (host)
+        hipLaunchKernelGGL((varlen_attn_combine2_kernel<T, D, true>), cgrid, cblock, 0, stream, w.part_o, w.part_ml, k_len, k_len_offset,
+                           hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
     else
-        hipLaunchKernelGGL((varlen_attn_split_kernel<T, D, false>), dim3(n_splits, Hkv, n_rtiles), dim3(AT_THREADS), 0, stream,
-                           reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v),
-                           k_start, k_len, k_len_offset, G, q_len, chunk, scale, causal, part_o, part_ml, n_splits, n_rtiles,
-                           (const T*)nullptr, (const T*)nullptr, (int64_t)0, (int64_t)0);
-    KVZ_CHECK_LAUNCH("varlen_attn_split_kernel");
-    hipLaunchKernelGGL((varlen_attn_combine_kernel<T, D>), dim3(Hkv, n_rtiles, AT_RT), dim3(CB_THREADS), 0, stream, part_o,
-                       part_ml, k_len, k_len_offset, G, q_len, chunk, n_splits, n_rtiles, reinterpret_cast<T*>(out));
-    KVZ_CHECK_LAUNCH("varlen_attn_combine_kernel");
+        hipLaunchKernelGGL((varlen_attn_combine2_kernel<T, D, false>), cgrid, cblock, 0, stream, w.part_o, w.part_ml, k_len, k_len_offset,
+                           hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
+    KVZ_CHECK_LAUNCH("varlen_attn_combine2_kernel");
     return KVZ_OK;
 }
 
@@ -375,55 +450,54 @@ using namespace kvz;
 
 extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0 || max_len_k < 0) return 0;
-    const int chunk = attn_chunk(Hkv, max_len_k);
-    int n_splits = (max_len_k + chunk - 1) / chunk;
-    if (n_splits < 1) n_splits = 1;
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
-    return (size_t)Hkv * n_rtiles * n_splits * AT_RT * (D + 2) * sizeof(float);
+    return attn_ws(nullptr, Hkv, n_rtiles, D).bytes;
 }
 
 extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, const int32_t* k_start,
-                               const int32_t* k_len, int k_len_offset, int Hkv, int G, int q_len, int D,
-                               int max_len_k, float scale,
+                               const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int q_len,
+                               int D, int max_len_k, float scale,
                                int causal, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && v && k_start && k_len && out && ws, KVZ_EINVAL, "kvz_varlen_attn: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0 && max_len_k >= 0, KVZ_EINVAL, "kvz_varlen_attn: bad shape");
     KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_varlen_attn: head_dim %d unsupported (64 or 128)", D);
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_varlen_attn: bad dtype %d", dtype);
-    KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), KVZ_EINVAL, "kvz_varlen_attn: q/k/v must be 16-byte aligned");
+    KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ws), KVZ_EINVAL,
+                "kvz_varlen_attn: q/k/v/ws must be 16-byte aligned");
     KVZ_REQUIRE((q_len * G + AT_RT - 1) / AT_RT <= 65535, KVZ_EINVAL, "kvz_varlen_attn: too many query rows");
     KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
                 "kvz_varlen_attn: workspace too small");
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
-        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
     }
-    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
-    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, Hkv, G, q_len, max_len_k, scale, causal, out, ws, stream);
+    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
 }
 
 extern "C" int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache, const void* k_state, const void* v_state,
                                       int64_t k_state_head_stride, int64_t v_state_head_stride, const int32_t* k_start,
-                                      const int32_t* k_len, int k_len_offset, int Hkv, int G, int D, int max_len_k,
-                                      float scale, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+                                      const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int D,
+                                      int max_len_k, float scale, int dtype, void* out, void* ws, size_t ws_bytes,
+                                      kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k_cache && v_cache && k_state && v_state && k_start && k_len && out && ws, KVZ_EINVAL,
                 "kvz_varlen_attn_append: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && max_len_k >= 1 && k_len_offset >= 0, KVZ_EINVAL, "kvz_varlen_attn_append: bad shape");
     KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_varlen_attn_append: head_dim %d unsupported (64 or 128)", D);
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_varlen_attn_append: bad dtype %d", dtype);
-    KVZ_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(k_state) && aligned16(v_state), KVZ_EINVAL,
-                "kvz_varlen_attn_append: pointers must be 16-byte aligned");
+    KVZ_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(k_state) && aligned16(v_state) && aligned16(ws),
+                KVZ_EINVAL, "kvz_varlen_attn_append: pointers must be 16-byte aligned");
     KVZ_REQUIRE((k_state_head_stride * 2) % 16 == 0 && (v_state_head_stride * 2) % 16 == 0, KVZ_EINVAL,
                 "kvz_varlen_attn_append: state head strides must be multiples of 8 elements");
     KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, 1, D, max_len_k), KVZ_EWORKSPACE,
                 "kvz_varlen_attn_append: workspace too small");
     const int off = k_len_offset + 1;  // the keys attended to include the token appended by this call
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_attn<_Float16, 128>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
-        return launch_attn<_Float16, 64>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+        if (D == 128) return launch_attn<_Float16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+        return launch_attn<_Float16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
     }
-    if (D == 128) return launch_attn<__bf16, 128>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
-    return launch_attn<__bf16, 64>(q, k_cache, v_cache, k_start, k_len, off, Hkv, G, 1, max_len_k, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    if (D == 128) return launch_attn<__bf16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    return launch_attn<__bf16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
 }

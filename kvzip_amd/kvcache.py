@@ -294,6 +294,16 @@ class EvictCache(_CacheBase):
             "rows_used": rows_used,
             "offset": [0 for _ in range(L)],                     # rows appended after pruning, per layer
         }
+        self._refresh_meta_host()
+
+    def _refresh_meta_host(self):
+        """ctypes copies [seg_start ++ len_k] per layer: passed by value to the attention kernel (slack layout only: in the packed
+        layout the segment starts move with every appended token and live on the device)."""
+        if self.layout != "slack":
+            self.info["meta_host"] = None
+            return
+        seg = torch.stack(self.info["seg_start"]).cpu().tolist() if self.info["seg_start"] else []
+        self.info["meta_host"] = [ops._meta_host(seg[l], self.info["len_k_host"][l], self.n_heads_kv) for l in range(self.n_layers)]
 
     def _grow_slack(self, need: int):
         """Re-lay out every layer with a larger slack (rare: only when more than ``slack`` tokens are appended)."""
@@ -317,6 +327,7 @@ class EvictCache(_CacheBase):
             self.key_cache[l], self.value_cache[l] = nk, nv
             self.info["seg_start"][l] = torch.tensor(starts, dtype=torch.int32, device=self.device)
         self.slack = new_slack
+        self._refresh_meta_host()
 
     # reference: kvcache.py:187-213
     def prepare(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
@@ -339,6 +350,7 @@ class EvictCache(_CacheBase):
             "k_start": self.info["seg_start"][layer_idx],
             "k_len": self.info["len_k"][layer_idx],
             "k_len_offset": self.info["offset"][layer_idx],
+            "meta_host": self._meta_host(layer_idx),
         }
         if self.layout == "packed":
             self.info["cu_len_k"][layer_idx] += cu_len_q
@@ -353,20 +365,28 @@ class EvictCache(_CacheBase):
         """Variable-length attention over the pruned cache: what the reference gets from
         ``flash_attn_varlen_func`` (attention/attn.py:61-71).  Returns ``[Hkv*q_len, G, D]``."""
         dim = query_states.shape[-1]
-        key = getattr(self, "_attn_ws_key", None)
-        if self._attn_ws is None or key is None or key[0] != info["max_len_q"] or info["max_len_k"] > key[1]:
-            # size the scratch for this query length and some growth of the keys; re-queried only when outgrown
-            cap = info["max_len_k"] + 4096
-            lib = ops._lib.load()
-            need = max(lib.kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, info["max_len_q"], dim, n)
-                       for n in (info["max_len_k"], cap))
-            self._attn_ws = torch.empty(2 * int(need) + 256, dtype=torch.uint8, device=query_states.device)
-            self._attn_ws_key = (info["max_len_q"], cap)
+        ws = self._attn_workspace(info["max_len_q"], dim, query_states.device)
         return ops.varlen_attn(query_states, key_states.view(-1, dim), value_states.view(-1, dim), info["k_start"],
                                info["k_len"], info["max_len_q"], info["max_len_k"], causal=causal,
-                               softmax_scale=softmax_scale, workspace=self._attn_ws,
-                               k_len_offset=info["k_len_offset"])
+                               softmax_scale=softmax_scale, workspace=ws,
+                               k_len_offset=info["k_len_offset"], meta_host=info.get("meta_host"))
 
+    def _attn_workspace(self, q_len: int, dim: int, device) -> torch.Tensor:
+        """Zero-initialised scratch of the attention kernel, one per query length (its size does not depend on the key lengths)."""
+        cache = getattr(self, "_attn_ws_cache", None)
+        if cache is None:
+            cache = self._attn_ws_cache = {}
+        ws = cache.get((q_len, dim))
+        if ws is None:
+            if len(cache) > 4:
+                cache.clear()
+            ws = cache[(q_len, dim)] = ops.attn_workspace(self.n_heads_kv, self.n_group_kv, q_len, dim, device)
+        return ws
+
+    def _meta_host(self, layer_idx: int):
+        """Head segments of a layer as kernel arguments (host copy made at prune / slack growth), or None."""
+        mh = self.info.get("meta_host")
+        return mh[layer_idx] if mh is not None else None
 
     def update_attend(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int,
                       softmax_scale: Optional[float] = None) -> torch.Tensor:
@@ -382,17 +402,11 @@ class EvictCache(_CacheBase):
             self._grow_slack(off + 1)
         dim = query_states.shape[-1]
         max_len_k = self.info["max_len_k"][layer_idx] + off + 1
-        key = getattr(self, "_attn_ws_key", None)
-        if self._attn_ws is None or key is None or key[0] != 1 or max_len_k > key[1]:
-            cap = max_len_k + 4096
-            lib = ops._lib.load()
-            need = max(lib.kvz_varlen_attn_workspace_bytes(self.n_heads_kv, self.n_group_kv, 1, dim, n) for n in (max_len_k, cap))
-            self._attn_ws = torch.empty(2 * int(need) + 256, dtype=torch.uint8, device=query_states.device)
-            self._attn_ws_key = (1, cap)
+        ws = self._attn_workspace(1, dim, query_states.device)
         out = ops.varlen_attn_append(query_states.reshape(-1, self.n_group_kv, dim), self.key_cache[layer_idx],
                                      self.value_cache[layer_idx], key_states, value_states,
                                      self.info["seg_start"][layer_idx], self.info["len_k"][layer_idx], off, max_len_k,
-                                     softmax_scale=softmax_scale, workspace=self._attn_ws)
+                                     softmax_scale=softmax_scale, workspace=ws, meta_host=self._meta_host(layer_idx))
         self.info["offset"][layer_idx] = off + 1
         return out
 
@@ -464,4 +478,5 @@ class RetainCache(_CacheBase):
         return query_states, k_flat.view(-1, 1, dim), v_flat.view(-1, 1, dim), info
 
     attend = EvictCache.attend
+    _attn_workspace = EvictCache._attn_workspace
     _attn_ws = None

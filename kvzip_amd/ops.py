@@ -304,11 +304,27 @@ def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.
 # --------------------------------------------------------------------------------------------------
 # a13  variable-length attention
 # --------------------------------------------------------------------------------------------------
+def attn_workspace(Hkv: int, G: int, q_len: int, D: int, device) -> torch.Tensor:
+    """Scratch of the attention kernel: partial results of the key ranges + one arrival counter per (head, row tile).  It must be
+    ZERO-FILLED when first used (every call leaves the counters at zero), so it is allocated with torch.zeros."""
+    need = _lib.load().kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, 0)
+    return torch.zeros(max(int(need), 16), dtype=torch.uint8, device=device)
+
+
+def _meta_host(k_start_host, k_len_host, Hkv):
+    """ctypes int32 array [starts ++ lens] for the kernel arguments, or None."""
+    if k_start_host is None or k_len_host is None or Hkv > 64:
+        return None
+    import ctypes as C
+    return (C.c_int32 * (2 * Hkv))(*k_start_host, *k_len_host)
+
+
 def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor,
                 q_len: int, max_len_k: int, causal: bool = True, softmax_scale: Optional[float] = None,
-                workspace: Optional[torch.Tensor] = None, k_len_offset: int = 0) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, k_len_offset: int = 0, meta_host=None) -> torch.Tensor:
     """q ``[Hkv*q_len, G, D]``; k, v ``[rows, D]`` (or ``[rows, 1, D]``); head h owns rows
-    ``k_start[h] : k_start[h]+k_len[h]``.  Returns ``[Hkv*q_len, G, D]``."""
+    ``k_start[h] : k_start[h]+k_len[h]``.  Returns ``[Hkv*q_len, G, D]``.  ``meta_host``: ctypes array from
+    ``_meta_host`` (the segments as the host knows them) or None; ``workspace`` from ``attn_workspace``."""
     lib = _lib.load()
     HQ, G, D = q.shape
     Hkv = HQ // q_len
@@ -318,10 +334,9 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
     out = torch.empty_like(q)
     if workspace is None:  # (a caller-provided workspace is validated by the library itself: KVZ_EWORKSPACE)
-        need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, int(max_len_k))
-        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+        workspace = attn_workspace(Hkv, G, q_len, D, q.device)
     rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(),
-                             int(k_len_offset), Hkv, G,
+                             int(k_len_offset), meta_host, Hkv, G,
                              q_len, D, int(max_len_k), float(scale), 1 if causal else 0, _dtype_code(q.dtype),
                              out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
     check(rc, "kvz_varlen_attn")
@@ -330,7 +345,8 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
 
 def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.Tensor,
                        v_state: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor, k_len_offset: int, max_len_k: int,
-                       softmax_scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       softmax_scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None,
+                       meta_host=None) -> torch.Tensor:
     """Decode step in one launch: append the new token's K, V (``[1, Hkv, 1, D]``, any head stride) to the per-head slack
     of the flat cache and attend ``q`` (``[Hkv, G, D]``) over ``k_len + k_len_offset + 1`` keys.  ``k_len_offset`` counts the
     tokens appended BEFORE this call.  Bit-identical to ``append_inplace`` followed by ``varlen_attn``."""
@@ -342,11 +358,10 @@ def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Te
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
     out = torch.empty_like(q)
     if workspace is None:
-        need = lib.kvz_varlen_attn_workspace_bytes(Hkv, G, 1, D, int(max_len_k))
-        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+        workspace = attn_workspace(Hkv, G, 1, D, q.device)
     rc = lib.kvz_varlen_attn_append(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(),
                                     v_state.data_ptr(), k_state.stride(-3), v_state.stride(-3), k_start.data_ptr(),
-                                    k_len.data_ptr(), int(k_len_offset), Hkv, G, D, int(max_len_k), float(scale),
+                                    k_len.data_ptr(), int(k_len_offset), meta_host, Hkv, G, D, int(max_len_k), float(scale),
                                     _dtype_code(q.dtype), out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
     check(rc, "kvz_varlen_attn_append")
     return out

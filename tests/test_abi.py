@@ -46,12 +46,15 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from kvzip_amd import _lib
     lib = _lib.load()
-    assert lib.kvz_abi_version() == 1
+    assert lib.kvz_abi_version() == 2
     assert lib.kvz_select_workspace_bytes() >= (2048 + 32) * 4
     assert lib.kvz_compact_plan_bytes(28, 4, 131104) == 28 * 4 * 129 * 4
     assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000, 32) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4
     assert lib.kvz_varlen_attn_workspace_bytes(4, 7, 1, 128, 131104) > 0
     assert lib.kvz_score_workspace_bytes(0, 7, 1, 1, 0) == 0
+    # asynchronous-scoring contexts are host objects (events): creating / destroying them needs no kernel
+    assert lib.kvz_async_create(0) < 0 and b"slot" in lib.kvz_last_error()
+    assert lib.kvz_async_wait(12345, -1, None) < 0 and lib.kvz_async_destroy(12345) == 0
 
 
 def test_argument_validation_without_gpu():
@@ -60,7 +63,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.kvz_select_threshold(None, 10, 0.3, 0, None, 10, None, None, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.kvz_last_error()
-    rc = lib.kvz_varlen_attn(16, 16, 16, 16, 16, 0, 2, 7, 1, 96, 10, 0.1, 1, 0, 16, 16, 1 << 30, None)
+    rc = lib.kvz_varlen_attn(16, 16, 16, 16, 16, 0, None, 2, 7, 1, 96, 10, 0.1, 1, 0, 16, 16, 1 << 30, None)
     assert rc == -4 and b"head_dim" in lib.kvz_last_error()
     with pytest.raises(_lib.KvzError):
         _lib.check(rc, "kvz_varlen_attn")

@@ -562,6 +562,47 @@ def test_varlen_attn_long_ragged_vs_oracle(q_len):
     assert (got - want).abs().max() <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
+    """The one-launch attention: work items cut from the SUM of very ragged head lengths (AdaKV-style budgets, a dropped head,
+    an empty head), head segments given as kernel arguments or read from the device arrays, the SAME workspace reused call
+    after call (the arrival counters must come back to zero), fused append variant included.  Oracle tolerance 1e-3 (fp16)."""
+    from kvzip_amd import ops
+    Hkv, G, D = 6, 7, 128
+    lens = [39000, 17, 120000, 500, 0, 4100]
+    slack = 8
+    starts, acc = [], 0
+    for n in lens:
+        starts.append(acc)
+        acc += n + slack
+    g = torch.Generator(device=DEV).manual_seed(21)
+    k = torch.randn(acc, D, generator=g, device=DEV).to(dtype)
+    v = torch.randn(acc, D, generator=g, device=DEV).to(dtype)
+    ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3
+    ws = ops.attn_workspace(Hkv, G, 1, D, DEV)
+    meta = ops._meta_host(starts, lens, Hkv)
+    for it in range(4):
+        q = torch.randn(Hkv, G, D, generator=g, device=DEV).to(dtype)
+        want = orc.varlen_attn(q.cpu(), k.cpu(), v.cpu(), starts, lens, 1).float()
+        a = ops.varlen_attn(q, k, v, ks, kl, 1, max(lens), workspace=ws, meta_host=meta if it % 2 == 0 else None)
+        assert (a.cpu().float() - want).abs().max() <= tol, it
+        assert torch.equal(a[4].cpu().float(), torch.zeros(G, D))  # the empty head: zeros, like flash-attn
+    # fused append on the same workspace: one new token per head, then the same answer as append + attention
+    kn = torch.randn(1, Hkv, 1, D, generator=g, device=DEV).to(dtype)
+    vn = torch.randn(1, Hkv, 1, D, generator=g, device=DEV).to(dtype)
+    q = torch.randn(Hkv, G, D, generator=g, device=DEV).to(dtype)
+    k2, v2 = k.clone(), v.clone()
+    got = ops.varlen_attn_append(q, k, v, kn, vn, ks, kl, 0, max(lens) + 1, workspace=ws, meta_host=meta)
+    ops.append_inplace(k2, v2, kn, vn, ks, kl, 0)
+    ref = ops.varlen_attn(q, k2, v2, ks, kl, 1, max(lens) + 1, k_len_offset=1)
+    assert torch.equal(got, ref) and torch.equal(k, k2) and torch.equal(v, v2)
+    lens1 = [n + 1 for n in lens]
+    want = orc.varlen_attn(q.cpu(), k2.cpu(), v2.cpu(), starts, lens1, 1).float()
+    assert (got.cpu().float() - want).abs().max() <= tol
+
+
 def test_flash_attn_varlen_func_call_compatibility():
     """ops.flash_attn_varlen_func takes the reference's call (attention/attn.py:61-71: q [Hkv*q_len, G, D], k/v [rows, 1, D],
     cu_seqlens_q/k, max lengths, causal=True) and returns what the oracle's restatement of flash-attn's semantics returns."""

@@ -40,12 +40,13 @@ elif what == "attn":
     k = torch.randn(rows, D, generator=g, device=dev).to(dt)
     v = torch.randn(rows, D, generator=g, device=dev).to(dt)
     q = torch.randn(Hkv, G, D, generator=g, device=dev).to(dt)
+    ws = ops.attn_workspace(Hkv, G, 1, D, dev)
     for _ in range(2):
-        ops.varlen_attn(q, k, v, starts, lens, 1, 39900)
+        ops.varlen_attn(q, k, v, starts, lens, 1, 39900, workspace=ws)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        ops.varlen_attn(q, k, v, starts, lens, 1, 39900)
+        ops.varlen_attn(q, k, v, starts, lens, 1, 39900, workspace=ws)
     torch.cuda.synchronize()
     print(f"varlen_attn: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
 elif what == "compact":
