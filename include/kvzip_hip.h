@@ -271,6 +271,28 @@ int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache,
                            int Hkv, int G, int D, int max_len_k, float scale, int dtype,
                            void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
 
+/* f2 + a13 with q_len > 1: causal GQA attention of R = q_len*G query rows per KV head over that head's key segment, keys
+ * walked once per 128-row block (LDS-shared 64-key tiles, MFMA 16x16x32, online softmax).  Replaces
+ *   flash_attn_func(query, key, value, causal=True)            reference attention/attn.py:75-89 (dense pre-prune forward;
+ *                                                              head h owns rows h*capacity .. of the dense cache), and
+ *   flash_attn_varlen_func(..., max_seqlen_q = q_len > 1)      reference attention/attn.py:61-71 (first generation step on a
+ *                                                              pruned cache; kvz_varlen_attn forwards here when q_len*G > 16).
+ * Element (h, g, i) of the query sits at  q + h*q_stride_head + g*q_stride_group + i*q_stride_pos  (same for out), so both
+ * [Hkv*q_len, G, D] and [H, q_len, D] are addressed without a re-layout copy; D contiguous.  k, v: [rows, D]; head h owns rows
+ * k_start[h] .. +k_len[h]+k_len_offset (device arrays, or k_meta_host = {start[Hkv], len[Hkv]} by value, up to 64 heads; either
+ * may be NULL if the other is given).  Causal mask aligned bottom-right: position i sees keys j <= i + len_h - q_len.
+ * lse_out: NULL or float [Hkv, q_len*G] (row i*G+g): natural-log LSE of the scaled logits, -inf for rows that see no key.
+ * ws: NULL, or kvz_flash_workspace_bytes(...) bytes (no initialisation needed).  With few query rows (fewer than 256 blocks of
+ * 128 rows over all heads) the keys of a head are split over up to 64 blocks whose partial results a second launch merges; that
+ * needs the workspace.  Without one every block walks all keys of its head (correct, slower for few rows). */
+size_t kvz_flash_workspace_bytes(int Hkv, int G, int q_len, int D);
+int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos,
+                  const void* k, const void* v,
+                  const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
+                  int Hkv, int G, int q_len, int D, float scale, int causal, int dtype,
+                  void* out, int64_t o_stride_head, int64_t o_stride_group, int64_t o_stride_pos,
+                  float* lse_out, void* ws, size_t ws_bytes, kvz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

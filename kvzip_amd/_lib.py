@@ -49,6 +49,9 @@ SIGNATURES = {
     "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
     "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp,
                                     _sz, _vp]),
+    "kvz_flash_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "kvz_flash_fwd": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _i64, _i64,
+                           _i64, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

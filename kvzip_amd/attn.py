@@ -7,9 +7,9 @@ interface registry).  Hooks on the cache object, in this order (attention/attn.p
     prepare()+attend()  variable-length attention over the pruned KV   (if cache.pruned)
     update_attend()     the three of them in one launch                (generation step on a pruned slack-layout cache)
 
-The dense (pre-prune) attention is NOT on the eviction hot path; the reference delegates it to flash-attn's dense
-kernel (attention/attn.py:75-89).  Here it goes through torch SDPA, registered as the attention implementation
-``"kvzip_hip"`` so that transformers skips its own mask construction (bottom-right aligned causal mask built here).
+The dense (pre-prune) attention — flash-attn's dense kernel in the reference (attention/attn.py:75-89) — runs on the
+library's multi-row kernel (``ops.flash_fwd`` -> ``kvz_flash_fwd``), registered as the attention implementation
+``"kvzip_hip"`` so that transformers skips its own mask construction (the kernel aligns the causal mask bottom-right).
 """
 from __future__ import annotations
 
@@ -22,15 +22,19 @@ import torch.nn.functional as F
 def dense_causal_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
                            scaling: Optional[float] = None, **kwargs):
     """[b, H, q, D] x [b, Hkv, k, D] -> ([b, q, H, D], None); causal mask aligned to the bottom-right corner
-    (query i sees keys j <= i + k - q), like flash-attn's dense kernel used by the reference."""
+    (query i sees keys j <= i + k - q), like flash-attn's dense kernel used by the reference (attention/attn.py:75-89).
+    Runs on the library's own multi-row kernel (``kvz_flash_fwd``) straight off the dense cache views; torch SDPA only
+    for what that kernel does not take (CPU tensors, fp32, head dims other than 64 / 128, batch > 1)."""
     q_len, k_len = query.shape[-2], key.shape[-2]
     G = query.shape[1] // key.shape[1]
+    if (query.is_cuda and query.dtype in (torch.float16, torch.bfloat16) and query.shape[0] == 1
+            and query.shape[-1] in (64, 128) and key.shape[1] <= 64):
+        from . import ops
+        return ops.flash_fwd(query, key, value, causal=True, softmax_scale=scaling), None
     mask, causal = None, False
     if q_len == k_len:
         causal = q_len > 1
     elif q_len > 1:
-        # bottom-right aligned causal mask as a BIAS OBJECT, never a materialised [q, k] tensor: a dense boolean mask is
-        # 270 MB per layer call at q = 2026, k = 133 k and rules out the flash / memory-efficient backends
         from torch.nn.attention.bias import causal_lower_right
         mask = causal_lower_right(q_len, k_len)
     out = F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scaling,

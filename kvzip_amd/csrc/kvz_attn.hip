@@ -80,13 +80,13 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
     int chunk = (total + target_items - 1) / target_items;
     chunk = (chunk + 127) / 128 * 128;
     if (chunk < 128) chunk = 128;
-    int h = -1, split = 0, nsp = 0, first_item = 0;
+    int h = -1, split = 0, first_item = 0;
     {
         int b = blockIdx.x, items = 0;
         for (int hh = 0; hh < Hkv; ++hh) {
             const int n = max(1, (len_of(hh) + chunk - 1) / chunk);  // (an empty head still gets one item: it writes zeros)
             if (h < 0) {
-                if (b < n) { h = hh; split = b; nsp = n; first_item = items; }
+                if (b < n) { h = hh; split = b; first_item = items; }
                 else b -= n;
             }
             items += n;
@@ -448,8 +448,19 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
 
 using namespace kvz;
 
+// query rows per head above which the multi-row kernel takes over from the split-key decode kernel (KVZ_FLASH_MIN_ROWS)
+static int flash_min_rows() {
+    static const int v = [] {
+        const char* e = getenv("KVZ_FLASH_MIN_ROWS");
+        const int x = e ? atoi(e) : 0;
+        return x > 0 ? x : 64;
+    }();
+    return v;
+}
+
 extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0 || max_len_k < 0) return 0;
+    if (q_len * G > flash_min_rows()) return kvz_flash_workspace_bytes(Hkv, G, q_len, D) + 256;  // (never 0: callers pass a buffer)
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
     return attn_ws(nullptr, Hkv, n_rtiles, D).bytes;
 }
@@ -465,6 +476,13 @@ extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, cons
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_varlen_attn: bad dtype %d", dtype);
     KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ws), KVZ_EINVAL,
                 "kvz_varlen_attn: q/k/v/ws must be 16-byte aligned");
+    if (q_len * G > flash_min_rows()) {  // many query rows: one pass over the keys per 128-row block (kvz_flash.hip)
+        KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
+                    "kvz_varlen_attn: workspace too small");
+        return kvz_flash_fwd(q, (int64_t)q_len * G * D, D, (int64_t)G * D, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G,
+                             q_len, D, scale, causal, dtype, out, (int64_t)q_len * G * D, D, (int64_t)G * D, nullptr, ws, ws_bytes,
+                             stream_);
+    }
     KVZ_REQUIRE((q_len * G + AT_RT - 1) / AT_RT <= 65535, KVZ_EINVAL, "kvz_varlen_attn: too many query rows");
     KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
                 "kvz_varlen_attn: workspace too small");

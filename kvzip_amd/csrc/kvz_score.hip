@@ -841,7 +841,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
     constexpr int RING = 3;  // key-tile buffers: tile p of the block's stream lives in buffer p % 3 (160 KiB of LDS at D = 128)
     __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
-    char* const qarea = lds + RING * C::TILE_BYTES;
     constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
     constexpr float L2E = 1.44269504088896340736f;
     constexpr int NB = SC_TILE / 32;  // 32-key blocks per tile

@@ -367,6 +367,41 @@ def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Te
     return out
 
 
+def flash_fwd(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, causal: bool = True,
+              softmax_scale: Optional[float] = None, return_lse: bool = False):
+    """Dense GQA attention ``[1, H, q, D] x [1, Hkv, k, D] -> [1, q, H, D]`` with the causal mask aligned bottom-right
+    (reference attention/attn.py:75-89, flash-attn's dense kernel).  ``key`` / ``value`` may be views of the dense cache
+    (any head stride, rows contiguous); nothing is copied.  ``return_lse``: also the fp32 row LSE ``[1, H, q]``."""
+    lib = _lib.load()
+    b, H, q_len, D = query.shape
+    Hkv, klen = key.shape[1], key.shape[2]
+    G = H // Hkv
+    assert b == 1 and key.shape[0] == 1 and G * Hkv == H and value.shape == key.shape
+    if query.stride(-1) != 1 or query.stride(1) % 8 or query.stride(2) % 8:
+        query = query.contiguous()
+
+    def rows(t):  # [1, Hkv, k, D] view -> usable as "[rows, D], head h starts at row h * step"
+        return t.stride(-1) == 1 and t.stride(2) == D and t.stride(1) % D == 0
+    if not (rows(key) and rows(value) and key.stride(1) == value.stride(1)):
+        key, value = key.contiguous(), value.contiguous()
+    step = key.stride(1) // D if Hkv > 1 else klen
+    meta = _meta_host([h * step for h in range(Hkv)], [klen] * Hkv, Hkv)
+    assert meta is not None, "flash_fwd: more than 64 KV heads"
+    out = torch.empty(1, q_len, H, D, dtype=query.dtype, device=query.device)
+    lse = torch.empty(1, Hkv, q_len, G, dtype=torch.float32, device=query.device) if return_lse else None
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    need = int(lib.kvz_flash_workspace_bytes(Hkv, G, q_len, D))  # > 0 only when there are too few query rows to fill the chip
+    ws = torch.empty(need, dtype=torch.uint8, device=query.device) if need else None
+    rc = lib.kvz_flash_fwd(query.data_ptr(), G * query.stride(1), query.stride(1), query.stride(2), key.data_ptr(),
+                           value.data_ptr(), None, None, 0, meta, Hkv, G, q_len, D, float(scale), 1 if causal else 0,
+                           _dtype_code(query.dtype), out.data_ptr(), G * D, D, H * D, _ptr(lse), _ptr(ws), need,
+                           _stream(query))
+    check(rc, "kvz_flash_fwd")
+    if return_lse:
+        return out, lse.permute(0, 1, 3, 2).reshape(1, H, q_len)
+    return out
+
+
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
                            softmax_scale=None, causal=False, seqused_k=None):
     """Call-compatible stand-in for the reference's use of ``flash_attn.flash_attn_varlen_func``

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import kvzip_oracle as orc
-from conftest import from_bits, load_golden, to_bits, ulp_diff
+from conftest import ROOT, from_bits, load_golden, to_bits, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -601,6 +601,82 @@ def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
     lens1 = [n + 1 for n in lens]
     want = orc.varlen_attn(q.cpu(), k2.cpu(), v2.cpu(), starts, lens1, 1).float()
     assert (got.cpu().float() - want).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("q_len", [64, 257])
+def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
+    """First generation step on a pruned cache (q_len = len(query) > 1, reference model/wrapper.py:271-274): kvz_varlen_attn
+    hands q_len*G > 64 rows to the multi-row kernel (one pass over the keys per 128-row block).  Ragged heads incl. one that
+    holds only the new tokens, device arrays and by-value segments.  Oracle tolerance 1e-3 (fp16) / 8e-3 (bf16) absolute plus
+    one output ulp (2^-10 / 2^-7 relative): rows that see a handful of keys return values of magnitude 2-4, where the fp16
+    grid itself is 2e-3 wide."""
+    from kvzip_amd import ops
+    Hkv, G, D = 4, 7, 128
+    lens = [4097 + q_len, 33 + q_len, 1500 + q_len, q_len]
+    g = torch.Generator().manual_seed(q_len)
+    starts, tot = [], 0
+    for ln in lens:
+        starts.append(tot)
+        tot += ln + 5
+    q = torch.randn(Hkv * q_len, G, D, generator=g).to(dtype)
+    k = torch.randn(tot, D, generator=g).to(dtype)
+    v = torch.randn(tot, D, generator=g).to(dtype)
+    want = orc.varlen_attn(q, k, v, starts, lens, q_len).float()
+    ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    for meta in (None, ops._meta_host(starts, lens, Hkv)):
+        got = ops.varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), ks, kl, q_len, max(lens), meta_host=meta).cpu().float()
+        assert ((got - want).abs() <= tol + rel * want.abs()).all(), float((got - want).abs().max())
+    # the decode kernel (16-row tiles, split keys) must agree with the multi-row kernel on the same call
+    if q_len == 64:
+        import os
+        import subprocess
+        import sys
+        code = ("import torch, sys; sys.path.insert(0, %r); from kvzip_amd import ops; torch.manual_seed(0);"
+                "q=torch.randn(4*64,7,128,device='cuda').half(); k=torch.randn(9000,128,device='cuda').half();"
+                "v=torch.randn(9000,128,device='cuda').half(); ks=torch.tensor([0,3000,5000,8000],dtype=torch.int32,device='cuda');"
+                "kl=torch.tensor([2900,1900,2500,64],dtype=torch.int32,device='cuda');"
+                "o=ops.varlen_attn(q,k,v,ks,kl,64,2900); print(float(o.float().abs().sum()))" % ROOT)
+        outs = []
+        for rows in ("64", "100000"):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                               env={**os.environ, "KVZ_FLASH_MIN_ROWS": rows})
+            assert r.returncode == 0, r.stderr[-800:]
+            outs.append(float(r.stdout.strip().splitlines()[-1]))
+        assert abs(outs[0] - outs[1]) <= 2e-4 * abs(outs[1]), outs
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(28, 4, 300, 300, 128), (28, 4, 130, 1500, 128), (8, 8, 65, 200, 64), (6, 2, 1, 77, 128)])
+def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
+    """f2, the dense pre-prune forward (reference attention/attn.py:75-89): [1,H,q,D] x [1,Hkv,k,D] views of a LARGER dense
+    cache (head stride = capacity), bottom-right causal mask, output [1,q,H,D]; plus the row LSE.  fp32 reference with the
+    same mask; tolerance 1e-3 (fp16) / 8e-3 (bf16) + one output ulp on the output, 1e-3 on the LSE."""
+    from kvzip_amd import ops
+    H, Hkv, q_len, klen, D = shape
+    G = H // Hkv
+    g = torch.Generator(device=DEV).manual_seed(q_len + klen)
+    cap = klen + 37
+    kc = torch.randn(1, Hkv, cap, D, generator=g, device=DEV).to(dtype)
+    vc = torch.randn(1, Hkv, cap, D, generator=g, device=DEV).to(dtype)
+    qq = torch.randn(1, q_len, H, D, generator=g, device=DEV).to(dtype).transpose(1, 2)  # non-contiguous, like q_proj().view()
+    key, val = kc[:, :, :klen], vc[:, :, :klen]
+    out, lse = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+    assert out.shape == (1, q_len, H, D) and lse.shape == (1, H, q_len)
+    s = torch.einsum("hid,hjd->hij", qq[0].float(), key[0].float().repeat_interleave(G, 0)) / math.sqrt(D)
+    i = torch.arange(q_len, device=DEV).view(1, q_len, 1)
+    j = torch.arange(klen, device=DEV).view(1, 1, klen)
+    s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
+    want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
+    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)  # + one output ulp, as above
+    assert ((out[0].float() - want).abs() <= tol + rel * want.abs()).all(), float((out[0].float() - want).abs().max())
+    assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
+    # the attention hook of the model forward goes through the same kernel
+    from kvzip_amd.attn import dense_causal_attention
+    out2, _ = dense_causal_attention(None, qq, key, val, scaling=1.0 / math.sqrt(D))
+    assert torch.equal(out2, out)
 
 
 def test_flash_attn_varlen_func_call_compatibility():
