@@ -39,10 +39,20 @@ template <typename T> struct Mfma32;
 template <> struct Mfma32<_Float16> {
     typedef h8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    // first MFMA of a chain (C = 0) written INTO the registers of `acc`: the tied operand keeps an accumulator in one physical
+    // register tuple for the whole kernel (left to the allocator every chain is a fresh 16-tuple, and under pressure the hunt
+    // for free aligned tuples spills the fragment registers).  No software wait states are needed after it: the next MFMA of
+    // the chain accumulates into exactly the same registers (back-to-back SrcC = vDst is interlocked).
+    __device__ static inline void mfma_first(f16v& acc, v8 a, v8 b) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "v"(b));
+    }
 };
 template <> struct Mfma32<__bf16> {
     typedef b8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static inline void mfma_first(f16v& acc, v8 a, v8 b) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "v"(b));
+    }
 };
 
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
@@ -57,6 +67,26 @@ constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget i
 #endif
 constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;  // pass A: key tiles per work item (4: 2 -> +9 % item switches, 8 -> +6 % imbalance)
 constexpr int SC_PERSISTENT_BLOCKS = 256;          // pass A: one persistent block per CU
+
+// division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
+// l = ceil(log2 d) (Granlund-Montgomery round-up method, exact for 31-bit numerators).  A 32-bit division costs ~20 instructions;
+// the item switch of pass A had nine of them, executed by all eight waves.
+struct FastDiv {
+    uint32_t d, m, sh;  // sh = l - 1; d == 1 is the identity (m = 0)
+    __host__ __device__ inline int div(int n) const { return m ? (int)(__umulhi_((uint32_t)n, m) >> sh) : n; }
+    __host__ __device__ inline int mod(int n) const { return n - div(n) * (int)d; }
+    __host__ __device__ static inline uint32_t __umulhi_(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+};
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = (uint32_t)d;
+    if (d <= 1) { f.m = 0; f.sh = 0; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    f.m = (uint32_t)((((uint64_t)1 << (31 + l)) + (uint64_t)d - 1) / (uint64_t)d);
+    f.sh = (uint32_t)(l - 1);
+    return f;
+}
 
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
@@ -73,6 +103,7 @@ struct ScoreArgs {
     int n_kv_heads;
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
+    FastDiv dq, dh, dz;  // q_len, Hkv, work items per key slice of pass A
 };
 
 // reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
@@ -348,6 +379,9 @@ constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
 #ifndef KVZ_PB_V2
 #define KVZ_PB_V2 1                             // same for the column-maximum kernel
 #endif
+#ifndef KVZ_PA_V3
+#define KVZ_PA_V3 0                             // 1: 64 rows per wave + exactly balanced static partition (kvz_score_pa3.h): measured
+#endif                                          // -2 % at D = 64, does not fit the register file at D = 128 - off
 #ifndef KVZ_PA_V2
 #define KVZ_PA_V2 1                             // 1: software-pipelined row-statistics kernel (round 2); 0: round-1 kernel
 #endif
@@ -725,6 +759,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
 #ifndef KVZ_PRIO          // 1: the second-dispatched half of a block gets priority in every other step (it loses VALU arbitration by age)
 #define KVZ_PRIO 1
 #endif
+#ifndef KVZ_CVT_IN_ASM    // 1: the first conversion of the chain inside the assembly block too
+#define KVZ_CVT_IN_ASM 1
+#endif
 #ifndef KVZ_CHAIN_MIX16   // 1: second rounding of the chain by v_fma_mixlo/hi_f16 (round 1); 0: fp32 product + v_cvt_pk_f16_f32
 #define KVZ_CHAIN_MIX16 0
 #endif
@@ -743,6 +780,25 @@ template <typename T, bool FAST>
 __device__ static inline void quad_args(float a0, float a1, float a2, float a3, uint32_t& xa, uint32_t& xb, float (&arg)[4],
                                         float c, float rcp, float L2E /* multiplier of x */, float neg_ml2 /* addend */) {
     if constexpr (std::is_same<T, _Float16>::value && FAST) {
+#if !KVZ_CHAIN_MIX16 && KVZ_CVT_IN_ASM
+        // the first rounding inside the block as well: left outside, the compiler converts all 16 accumulators at the top of the
+        // step and keeps the 8 packed results (and a copy per quad) alive - registers the 64-row kernel does not have
+        asm("v_cvt_pk_f16_f32 %[xa], %[a0], %[a1]\n\t"
+            "v_cvt_pk_f16_f32 %[xb], %[a2], %[a3]\n\t"
+            "v_fma_mix_f32 %[g0], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_pk_f16_f32 %[xa], %[g0], %[g1]\n\t"
+            "v_cvt_pk_f16_f32 %[xb], %[g2], %[g3]\n\t"
+            "v_fma_mix_f32 %[g0], %[xa], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
+            : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
+        return;
+#endif
         xa = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a0, a1}, h2v));
         xb = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a2, a3}, h2v));
 #if KVZ_CHAIN_MIX16
@@ -827,7 +883,7 @@ constexpr float PA2_SUM_LOW = 9.5367431640625e-07f;  // 2^-20: lower bound for t
 #endif
 
 #if KVZ_TRACE
-__device__ unsigned long long g_trace2[8 * 8 * 40 * 8];
+__device__ unsigned long long g_trace2[8 * 8 * 40 * 16];
 #define KVZ_STAMP(i) do { ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define KVZ_STAMP(i) do { } while (0)
@@ -864,12 +920,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     auto decode = [&](int i) __attribute__((always_inline)) -> Item {
         Item it;
         it.k = 0;
-        it.z = i / per_z;
+        it.z = a.dz.div(i);
         const int rem = i - it.z * per_z;
-        it.rt = rem / a.n_kv_heads;
+        it.rt = a.dh.div(rem);
         it.h = rem - it.rt * a.n_kv_heads;
         const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
-        const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
+        const int h0 = a.dq.div(r0), h1 = a.dq.div(r1);
+        const int qmax = (h0 == h1) ? (r1 - h1 * a.q_len) : (a.q_len - 1);
         const int ntiles = (min(KT, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
         it.t_lo = it.z * SC_KSPLIT_TILES;
         it.t_hi = min(ntiles, it.t_lo + SC_KSPLIT_TILES);
@@ -936,20 +993,36 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             const uint32_t buf = lds0 + (uint32_t)(RING * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
             const int r0 = it.rt * PA_ROWS + (wave * PA_RG + g) * 32;
             const int rc0 = min(r0, R - 1);
-            const int g0 = rc0 / a.q_len, qi0 = rc0 - g0 * a.q_len;  // wave-uniform
+            const int g0 = a.dq.div(rc0), qi0 = rc0 - g0 * a.q_len;  // wave-uniform
+            if (a.q_len >= 32) {
+                // at most two query heads per group: a wave-uniform base, a shift for the row and one select for the rows that
+                // belong to the next head - no per-lane multiply or division (the generic form below costs ~38 instructions per
+                // piece, 1 500 cycles per item switch in the in-kernel timeline)
+                const uint32_t base = (uint32_t)(g0 * (int)hs + qi0 * C::ROW_BYTES);
+                const uint32_t wrapd = (uint32_t)((int)hs - a.q_len * C::ROW_BYTES);
+                const int nfirst = a.q_len - qi0;  // rows of the group that still lie in head g0
+                const int tail = R - 1 - rc0;      // rows beyond the last one shadow it
+                const int lrow = lane / C::CPR, pch = lane % C::CPR;
 #pragma unroll
-            for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
-                const int row = i * ROWS_PER_INSTR + lane / C::CPR;
-                const int pch = lane % C::CPR;
-                const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
-                int gg = g0, qi = qi0 + min(row, R - 1 - rc0);  // clamp to the last row
-                if (a.q_len >= 32) {
-                    if (qi >= a.q_len) { qi -= a.q_len; ++gg; }
-                } else {  // (tiny chunks only: a group of 32 rows spans several query heads)
-                    gg += qi / a.q_len;
-                    qi = qi % a.q_len;
+                for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+                    const int row = i * ROWS_PER_INSTR + lrow;
+                    const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                    const int rowc = min(row, tail);
+                    const uint32_t voff = base + (uint32_t)(rowc * C::ROW_BYTES + chunk * 16) + (rowc >= nfirst ? wrapd : 0u);
+                    lds_dma16a(qh, voff, buf + (uint32_t)(i * 1024));
                 }
-                lds_dma16a(qh, (uint32_t)(gg * (int)hs + qi * C::ROW_BYTES + chunk * 16), buf + (uint32_t)(i * 1024));
+            } else {  // (tiny chunks only: a group of 32 rows spans several query heads)
+#pragma unroll
+                for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+                    const int row = i * ROWS_PER_INSTR + lane / C::CPR;
+                    const int pch = lane % C::CPR;
+                    const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                    int gg = g0, qi = qi0 + min(row, R - 1 - rc0);  // clamp to the last row
+                    const int dg = a.dq.div(qi);
+                    gg += dg;
+                    qi -= dg * a.q_len;
+                    lds_dma16a(qh, (uint32_t)(gg * (int)hs + qi * C::ROW_BYTES + chunk * 16), buf + (uint32_t)(i * 1024));
+                }
             }
         }
     };
@@ -974,7 +1047,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         for (int g = 0; g < PA_RG; ++g) {
             w.r[g] = it.rt * PA_ROWS + (wave * PA_RG + g) * 32 + l31;
             const int rc = min(w.r[g], R - 1);
-            w.limit[g] = a.sink + a.m + rc % a.q_len;  // key j (virtual index) is visible to query i iff j <= sink + m + i  (score.py:67-85)
+            w.limit[g] = a.sink + a.m + a.dq.mod(rc);  // key j (virtual index) is visible to query i iff j <= sink + m + i  (score.py:67-85)
         }
         return w;
     };
@@ -1045,9 +1118,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     start_item();
 
 #if KVZ_TRACE
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 8..15: the item switch BEFORE this tile
     const bool tracing = (blockIdx.x % 32 == 5) && lane == 0;
-    unsigned long long* tr = g_trace2 + (((blockIdx.x / 32) % 8) * 8 + wave) * (40 * 8);
+    unsigned long long* tr = g_trace2 + (((blockIdx.x / 32) % 8) * 8 + wave) * (40 * 16);
     int tp = 0;
 #endif
     f16v acc[2][PA_RG];  // accumulators of block kb (index kb & 1)
@@ -1206,7 +1279,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_TRACE
         if (tracing && tp < 40) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tr[tp * 8 + i] = ts[i];
+            for (int i = 0; i < 16; ++i) tr[tp * 16 + i] = ts[i];
             ++tp;
         }
 #endif
@@ -1230,6 +1303,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         ++sp;
         ++t;
         if (t < cur.t_hi) continue;  // (acc[0] already holds block 0 of the next tile)
+        KVZ_STAMP(8);
 
         // ---- item finished: partial statistics of this key slice (reference m_ref, sum relative to fl(m_ref*log2e)) ----
 #pragma unroll
@@ -1248,19 +1322,26 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                 asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
             }
         }
+        KVZ_STAMP(9);
         if (!valid(nxt)) break;
         // ---- switch to the next item: fragments of its first two blocks are in registers, its query rows landed before the
         // last hand-over ----
         cur = nxt;
-        nxt = item_from(cur.k + 1);
-        t = cur.t_lo;
-        rows = rows_of(cur);
         read_q(bq);
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // rows in registers: the area is free again
+        KVZ_STAMP(10);
+        chain0(acc[0], fr[0]);  // (the eight dependent MFMAs run under the index arithmetic below)
+        KVZ_STAMP(11);
+        nxt = item_from(cur.k + 1);
+        t = cur.t_lo;
+        KVZ_STAMP(12);
+        rows = rows_of(cur);
+        KVZ_STAMP(13);
         if (valid(nxt)) stage_q(nxt);
+        KVZ_STAMP(14);
         if (sq_in_next) {  // the cursor was already inside the item that is now current
             sq_in_next = false;
             if (sq_done && valid(nxt)) {
@@ -1270,9 +1351,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             }
         }
         start_item();
-        chain0(acc[0], fr[0]);
+        KVZ_STAMP(15);
     }
 }
+
+#include "kvz_score_pa3.h"
 
 // merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
 // 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).  Only the slices below the causal limit of the row's tile exist.
@@ -1783,6 +1866,23 @@ template <typename T, int D, bool FAST>
 static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     const int R = a.G * a.q_len;
     a.n_kv_heads = Hkv;
+#if KVZ_PA_V3
+    {
+        PaPlan plan;
+        if (!p3_make_plan(plan, a.sink, a.m, a.q_len, a.G, Hkv)) {
+            set_error("kvz_score_chunk: more than 65535 (head, 512-row tile) units");
+            return KVZ_EUNSUPPORTED;
+        }
+        {
+            ProfScope ps("score_rowstat", stream);
+            hipLaunchKernelGGL((score_rowstat3_kernel<T, D, FAST>), dim3(plan.nb), dim3(P3_WAVES * 64), 0, stream, a, plan);
+        }
+        KVZ_CHECK_LAUNCH("score_rowstat3_kernel");
+        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
+        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total);
+        KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
+    }
+#else
     {
         const int items = (R + PA_ROWS - 1) / PA_ROWS * Hkv * a.key_splits;
         const int blocks = min(items, SC_PERSISTENT_BLOCKS);
@@ -1799,6 +1899,7 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, R, rows_total);
     }
     KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
+#endif
     const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     {
@@ -1827,7 +1928,12 @@ using namespace kvz;
 
 static inline int score_stats_stride(int G, int q_len) { return (G * q_len + SC_TILE - 1) / SC_TILE * SC_TILE; }
 static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
-    return align256((size_t)score_key_splits(sink, m, q_len) * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
+    int slices = score_key_splits(sink, m, q_len);
+#if KVZ_PA_V3
+    PaPlan plan;  // one partial per block that touches a 512-row tile
+    if (p3_make_plan(plan, sink, m, q_len, G, Hkv) && plan.max_seg > slices) slices = plan.max_seg;
+#endif
+    return align256((size_t)slices * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
 }
 
 static inline size_t score_colpart_bytes(int Hkv, int G, int q_len, int m) {
@@ -1865,6 +1971,9 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
+    a.dq = make_fastdiv(q_len);
+    a.dh = make_fastdiv(Hkv);
+    a.dz = make_fastdiv((G * q_len + PA_ROWS - 1) / PA_ROWS * Hkv);
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
     a.rcp = find_exact_reciprocal(D, dtype);
     if (dtype == KVZ_F16) {

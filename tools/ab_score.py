@@ -67,7 +67,7 @@ def child():
     Hkv, G, m, D, sink, N = 4, 7, 2000, 128, 32, 131072
     q_len = m + 26; klen = sink + N + q_len
     g = torch.Generator(device=dev).manual_seed(0)
-    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+    for dt, tag, D in ((torch.float16, "f16", 128), (torch.bfloat16, "bf16", 128), (torch.float16, "f16_d64", 64)):
         q = torch.randn(1, Hkv * G, q_len, D, generator=g, device=dev).to(dt); k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
         start = sink + 60000
         for _ in range(5): ops.score_chunk(q, k, sink, start, start + m)
