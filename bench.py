@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument("--prof-period", type=int, default=16,
                     help="every n-th scoring call of the timed region runs alone on the caller's stream with its kernels "
                          "bracketed by hipEvents (kernel durations for the roofline); the others overlap on the side streams")
-    ap.add_argument("--score-streams", type=int, default=2,
+    ap.add_argument("--score-streams", type=int, default=3,
                     help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
     args = ap.parse_args(argv)
     if args.ratio is None:

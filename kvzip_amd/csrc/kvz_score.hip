@@ -63,9 +63,12 @@ constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 12
 constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
 constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
 #ifndef KVZ_KSPLIT_TILES
-#define KVZ_KSPLIT_TILES 4
+#define KVZ_KSPLIT_TILES 8
 #endif
-constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;  // pass A: key tiles per work item (4: 2 -> +9 % item switches, 8 -> +6 % imbalance)
+// pass A: key tiles per work item.  Alone on the GPU 4 is fastest (8: +5 %, the tail of unevenly loaded blocks), but in the
+// scoring loop the calls of consecutive layers overlap and the tail is filled by the next kernel: there the WORK counts, and 8
+// halves the item switches (~3 000 cycles each, all eight waves): +6.5 % tokens/s in bench.py (16 and 32: +5 %).
+constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;
 constexpr int SC_PERSISTENT_BLOCKS = 256;          // pass A: one persistent block per CU
 
 // division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
@@ -881,6 +884,9 @@ constexpr float PA2_SUM_LOW = 9.5367431640625e-07f;  // 2^-20: lower bound for t
 #ifndef KVZ_TRACE
 #define KVZ_TRACE 0
 #endif
+#ifndef KVZ_ABL   // time-attribution builds of the row-statistics kernel (tools/abl_time.py; their results are garbage): bit 0 no
+#define KVZ_ABL 0  // fragment reads, 1 no exponentials, 2 no MFMA, 3 no staging, 4 no barrier, 5 no rounding chain
+#endif
 
 #if KVZ_TRACE
 __device__ unsigned long long g_trace2[8 * 8 * 40 * 16];
@@ -933,6 +939,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         return it;
     };
     const int G_ = gridDim.x;
+#if KVZ_ABL & 1
+    bool abl_first = true;
+#endif
     auto item_from = [&](int k) -> Item {
         Item it;
         it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
@@ -1053,6 +1062,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     };
     // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates
     auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
+#if KVZ_ABL & 1   // (time attribution only: the fragments are read once per item)
+        if (!abl_first) return;
+#endif
         frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
     };
     typedef std::integral_constant<int, 0> I0;
@@ -1102,18 +1114,24 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     int sp = 0;    // its position in the block's stream
     int t = cur.t_lo;
     float m_ref[PA_RG], nml2_ref[PA_RG], l_run[PA_RG];  // reference (16-bit value), -fl(reference * log2e), sum of 2^(x*log2e + nml2)
-    int wmin[PA_RG];
+    int wmin[PA_RG], t_hidden;  // t_hidden: first tile that no row of this wave sees
     auto start_item = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g) {
             m_ref[g] = 0.f;  // reference 0 until a block says otherwise: its sum of exponentials leaves [2^-20, 2^16] (first block
             nml2_ref[g] = 0.f;  // of the item: both bounds, later blocks: the upper one) -> cold path, reference = block maximum
             l_run[g] = 0.f;
-            int lo = rows.limit[g];
+            int lo = rows.limit[g], hi = rows.limit[g];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o, 64));
-            wmin[g] = __builtin_amdgcn_readfirstlane(lo);  // keys <= wmin are visible to every row of the group
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, __shfl_xor(lo, o, 64));
+                hi = max(hi, __shfl_xor(hi, o, 64));
+            }
+            wmin[g] = __builtin_amdgcn_readfirstlane(lo);  // keys <= wmin are visible to every row of the group,
+            const int th = __builtin_amdgcn_readfirstlane(hi) / SC_TILE + 1;  // keys beyond the largest limit to none
+            t_hidden = (g == 0) ? th : max(t_hidden, th);
         }
+        t_hidden = max(t_hidden, cur.t_lo + 1);
     };
     start_item();
 
@@ -1153,7 +1171,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
                     for (int g = 0; g < PA_RG; ++g) {
                         const int kk = MfmaSched<C::KK>::first(2 * qd) + c;
+#if KVZ_ABL & 4
+                        accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
+#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
+#endif
                     }
             }
 #pragma unroll
@@ -1164,7 +1186,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                     const int i = qd * 4 + j;
                     v[j] = (!MASK || (i & 3) + 8 * (i >> 2) <= rel[g]) ? accc[g][i] : -INFINITY;  // -inf survives the chain
                 }
+#if KVZ_ABL & 32
+                arg[g][0] = v[0]; arg[g][1] = v[1]; arg[g][2] = v[2]; arg[g][3] = v[3];
+                xp[g][2 * qd] = xp[g][2 * qd + 1] = 0;
+#else
                 quad_args<T, FAST>(v[0], v[1], v[2], v[3], xp[g][2 * qd], xp[g][2 * qd + 1], arg[g], a.c, a.rcp, L2E, nml2_ref[g]);
+#endif
             }
             // -- second half: (second MFMA,) the four exponentials and their sums
             __builtin_amdgcn_sched_barrier(0);
@@ -1174,11 +1201,20 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
                     for (int g = 0; g < PA_RG; ++g) {
                         const int kk = MfmaSched<C::KK>::first(2 * qd + 1) + c;
+#if KVZ_ABL & 4
+                        accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
+#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], accn[g]);
+#endif
                     }
             }
+#if KVZ_ABL & 2
+#pragma unroll
+            for (int g = 0; g < PA_RG; ++g) { ps0[g] += arg[g][0] + arg[g][2]; ps1[g] += arg[g][1] + arg[g][3]; }
+#else
 #pragma unroll
             for (int g = 0; g < PA_RG; ++g) quad_sum(arg[g], ps0[g], ps1[g]);
+#endif
             if (qd == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 hook();
@@ -1188,7 +1224,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g) {
             float ps = ps0[g] + ps1[g];
+#if KVZ_ABL
+            if (false) {
+#else
             if (__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0) {  // wave-uniform and rare: move the reference, redo
+#endif
                 asm volatile("" ::: "memory");                                                 // (keeps it a branch)
                 const float tmax = max_packed16<T>(xp[g]);
                 // up: a logit far above the reference; down (first block of an item only, nothing summed yet): all logits far below
@@ -1233,14 +1273,19 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             ++staged;
         }
         if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
+#if KVZ_ABL & 8
+            if (sp < 1)
+#endif
             sq_stage(B2);
             ++staged;
             newer = 1;
         }
         KVZ_STAMP(4);
+#if !(KVZ_ABL & 16)
         if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // the next tile (and older pieces) landed
         else stage_wait();
         block_barrier();  // ... everybody's part has, and nobody reads tile B any more
+#endif
         KVZ_STAMP(5);
         next_ready = staged >= sp + 2;
         if (next_ready) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
@@ -1292,11 +1337,41 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         if (masked) tile_steps(b_tag, std::true_type{});
         else tile_steps(b_tag, std::false_type{});
     };
+    // A tile that lies entirely behind the causal limit of every row of this wave (the item's tile range is cut at the limit of
+    // the LAST of its 256 rows; the waves holding the first rows see up to two such tiles per item, a whole key slice at worst):
+    // nothing to compute - every term would be exp(-inf) = 0 - but the wave still stages its share of the tiles ahead and
+    // takes part in the hand-over.  All later tiles of the item are hidden too, and the next item starts with its own chain0.
+    // One copy of the code for all ring positions (fragment offsets at run time: 16 extra additions per skipped tile).
+    auto tile_skip = [&]() __attribute__((always_inline)) {
+        const int b1 = (pbuf == RING - 1) ? 0 : pbuf + 1, b2 = (b1 == RING - 1) ? 0 : b1 + 1;
+        int newer = 0;
+        if (staged < sp + 2 && !sq_done) {
+            sq_stage(b1);
+            ++staged;
+        }
+        if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
+            sq_stage(b2);
+            ++staged;
+            newer = 1;
+        }
+        if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else stage_wait();
+        block_barrier();
+        next_ready = staged >= sp + 2;
+        if (next_ready) {
+            frag_load<D>(fr[0], fa0, b1 * C::TILE_BYTES);
+            frag_load<D>(fr[1], fa0, b1 * C::TILE_BYTES + 32 * C::ROW_BYTES);
+        }
+    };
     (void)diag0;
 
     chain0(acc[0], fr[0]);
+#if KVZ_ABL & 1
+    abl_first = false;
+#endif
     while (true) {
-        if (pbuf == 0) tile_dispatch(I0{});
+        if (t >= t_hidden) tile_skip();
+        else if (pbuf == 0) tile_dispatch(I0{});
         else if (pbuf == 1) tile_dispatch(I1{});
         else tile_dispatch(I2{});
         pbuf = (pbuf == RING - 1) ? 0 : pbuf + 1;
