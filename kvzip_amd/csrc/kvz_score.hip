@@ -762,6 +762,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_ker
 #ifndef KVZ_PRIO          // 1: the second-dispatched half of a block gets priority in every other step (it loses VALU arbitration by age)
 #define KVZ_PRIO 1
 #endif
+#ifndef KVZ_BF16_PACKED   // 1: bf16 rounding chain on pairs (packed conversions and packed fp32 multiplies)
+#define KVZ_BF16_PACKED 1
+#endif
 #ifndef KVZ_CVT_IN_ASM    // 1: the first conversion of the chain inside the assembly block too
 #define KVZ_CVT_IN_ASM 1
 #endif
@@ -833,6 +836,24 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
             : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
             : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
 #endif
+    } else if constexpr (std::is_same<T, __bf16>::value && FAST && KVZ_BF16_PACKED) {
+        // bf16: there is no mixed-precision fma that reads a bf16 half, so every value goes f32 -> bf16 -> f32 twice.  Written on
+        // pairs: v_cvt_pk_bf16_f32 rounds two values per instruction, the way back is a shift / a mask, and the two fp32
+        // multiplications (by rcp, then by log2e with the addend) are packed v_pk_mul_f32 / v_pk_fma_f32: 16 instead of the 24
+        // instructions per four logits that the element-wise form compiles to.
+        typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+        auto round2 = [](f2v v) __attribute__((always_inline)) -> uint32_t {
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2v));
+        };
+        auto widen2 = [](uint32_t p) __attribute__((always_inline)) -> f2v {
+            return f2v{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+        };
+        const f2v r2 = {rcp, rcp}, l2 = {L2E, L2E}, n2 = {neg_ml2, neg_ml2};
+        const f2v p01 = widen2(round2(f2v{a0, a1})) * r2, p23 = widen2(round2(f2v{a2, a3})) * r2;
+        xa = round2(p01);
+        xb = round2(p23);
+        const f2v g01 = __builtin_elementwise_fma(widen2(xa), l2, n2), g23 = __builtin_elementwise_fma(widen2(xb), l2, n2);
+        arg[0] = g01[0]; arg[1] = g01[1]; arg[2] = g23[0]; arg[3] = g23[1];
     } else {
         const T x0 = round_chain_h<T, FAST>(a0, c, rcp), x1 = round_chain_h<T, FAST>(a1, c, rcp);
         const T x2 = round_chain_h<T, FAST>(a2, c, rcp), x3 = round_chain_h<T, FAST>(a3, c, rcp);
@@ -1296,23 +1317,31 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         constexpr int B1 = (B + 1) % RING;
         const int k0 = t * SC_TILE;
         KVZ_STAMP(0);
-#if KVZ_PRIO
-        // experiment: the second-dispatched half of the block loses VALU arbitration by age; give it priority in every other step
-        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+        // the second-dispatched half of the block loses VALU arbitration by age: KVZ_PRIO 1 gives it priority in steps 0 and 2,
+        // 2 in steps 0-2, 3 always (set once before the loop), 4 in steps 1 and 3
+        const bool young = wave >= NWAVES / 2;
+#if KVZ_PRIO == 1 || KVZ_PRIO == 2
+        if (young) __builtin_amdgcn_s_setprio(1);
 #endif
         step(acc[1], acc[0], fr[1], k0, (t == cur.t_lo) ? PA2_SUM_LOW : 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
-#if KVZ_PRIO
-        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(0);
+#if KVZ_PRIO == 1
+        if (young) __builtin_amdgcn_s_setprio(0);
+#elif KVZ_PRIO == 4
+        if (young) __builtin_amdgcn_s_setprio(1);
 #endif
         KVZ_STAMP(1);
         step(acc[0], acc[1], fr[0], k0 + 32, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
         KVZ_STAMP(2);
-#if KVZ_PRIO
-        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#if KVZ_PRIO == 1
+        if (young) __builtin_amdgcn_s_setprio(1);
+#elif KVZ_PRIO == 4
+        if (young) __builtin_amdgcn_s_setprio(0);
 #endif
         step(acc[1], acc[0], fr[1], k0 + 64, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
-#if KVZ_PRIO
-        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(0);
+#if KVZ_PRIO == 1 || KVZ_PRIO == 2
+        if (young) __builtin_amdgcn_s_setprio(0);
+#elif KVZ_PRIO == 4
+        if (young) __builtin_amdgcn_s_setprio(1);
 #endif
         KVZ_STAMP(3);
         // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
@@ -1320,6 +1349,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         step(acc[0], acc[1], fr[0], k0 + 96, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) {
             if (next_ready) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
         });
+#if KVZ_PRIO == 4
+        if (young) __builtin_amdgcn_s_setprio(0);
+#endif
         KVZ_STAMP(7);
 #if KVZ_TRACE
         if (tracing && tp < 40) {
@@ -1365,6 +1397,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     };
     (void)diag0;
 
+#if KVZ_PRIO == 3
+    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     chain0(acc[0], fr[0]);
 #if KVZ_ABL & 1
     abl_first = false;
@@ -1846,7 +1881,10 @@ static inline int score_key_splits(int sink, int m, int q_len) {
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
     const int ctiles = (m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
-    int splits = (PB_WAVES == 8 ? 256 : 512) / (ctiles * Hkv);  // one round of resident blocks (1 or 2 per CU) when the shape allows
+#ifndef KVZ_PB_BLOCKS
+#define KVZ_PB_BLOCKS (PB_WAVES == 8 ? 256 : 512)
+#endif
+    int splits = KVZ_PB_BLOCKS / (ctiles * Hkv);  // one round of resident blocks (1 or 2 per CU) when the shape allows
     if (splits > rtiles) splits = rtiles;
     if (splits < 1) splits = 1;
     const int per = (rtiles + splits - 1) / splits;

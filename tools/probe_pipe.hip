@@ -42,6 +42,13 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
     float src[16]; for (int i = 0; i < 16; ++i) src[i] = threadIdx.x * 0.01f + i;
     float p0 = 0.f, p1 = 0.f, arg[4] = {0.f, 0.f, 0.f, 0.f};
     const float l2e = 1.4426950408889634f, nm = -3.f;
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    for (int o = threadIdx.x * 16; o < 65536; o += blockDim.x * 16) *(u4*)(lds + o) = u4{0x3c003c00u, 0x3c003c00u, 0x38003800u, 0x34003400u};
+    __syncthreads();
+    u4 fr[2][8];
+    const int fo = (threadIdx.x & 63) * 16;
+    for (int k = 0; k < 8; ++k) { fr[0][k] = *(u4*)(lds + fo + k * 1024); fr[1][k] = *(u4*)(lds + fo + 8192 + k * 1024); }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; ++it) {
         if (MODE == 3) {
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < (MODE >= 4 ? 0 : 32); ++s) {
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 0 || MODE == 2) acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[s % NACC], 0, 0, 0);
             if (MODE != 0) {
@@ -62,6 +69,57 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 7 || MODE == 8) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16v& accn = acc[(st + 1) & 1];
+                const f16v& accc = acc[st & 1];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fr[st & 1][s]), b, accn, 0, 0, 0);
+                    const int q = (s >> 1) * 4;
+                    if ((s & 1) == 0) fillA(accc[q], accc[q + 1], accc[q + 2], accc[q + 3], rcp, l2e, nm, arg);
+                    else fillB(arg, p0, p1);
+                    if (s == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (MODE == 7) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) fr[(st + 1) & 1][k] = *(u4*)(lds + fo + ((it * 4 + st) & 3) * 16384 + k * 1024);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (MODE >= 4) {
+            // the kernel's real shape: steps of 8 slots; the chain of a step accumulates into one set while the fillers read the
+            // 16 values of the OTHER set (produced by the previous step's chain).  MODE 5: the values are first copied out of the
+            // accumulator registers (16 v_mov), MODE 6: the fillers read plain registers (control)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16v& accn = acc[(st + 1) & 1];
+                const f16v& accc = acc[st & 1];
+                float cp[16];
+                if (MODE == 5) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { cp[i] = accc[i]; asm volatile("" : "+v"(cp[i])); }
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, accn, 0, 0, 0);
+                    const int q = (s >> 1) * 4;
+                    if ((s & 1) == 0) {
+                        if (MODE == 4) fillA(accc[q], accc[q + 1], accc[q + 2], accc[q + 3], rcp, l2e, nm, arg);
+                        else if (MODE == 5) fillA(cp[q], cp[q + 1], cp[q + 2], cp[q + 3], rcp, l2e, nm, arg);
+                        else fillA(src[q], src[q + 1], src[q + 2], src[q + 3], rcp, l2e, nm, arg);
+                    } else {
+                        fillB(arg, p0, p1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float sacc = p0 + p1 + arg[0];
@@ -96,6 +154,11 @@ int main() {
             run<4, 2, 1>("interleaved, 4.5 fill/slot", d, c, 512);
             run<1, 3, 2>("burst 32 mfma then fillers", d, c, 512); run<4, 3, 2>("burst 32 mfma then fillers", d, c, 512);
         }
+        run<2, 6, 2>("pipelined, fillers on plain regs", d, c, threads);
+        run<2, 4, 2>("pipelined, fillers read other acc", d, c, threads);
+        run<2, 5, 2>("pipelined, other acc copied first", d, c, threads);
+        run<2, 8, 2>("pipelined, A operands in 2 reg sets", d, c, threads);
+        run<2, 7, 2>("pipelined, + 8 ds_read_b128 / step", d, c, threads);
     }
     printf("%s\n", hipGetErrorString(hipDeviceSynchronize()));
 }
