@@ -59,7 +59,7 @@ def test_config_c1_qwen05b_full_context():
     d = torch.stack([ulp_diff(kv.score[l], ref[l]) for l in range(L)])
     exact, within1 = float((d == 0).float().mean()), float((d <= 1).float().mean())
     print(f"C1 scores: {exact:.4f} bit-identical, {within1:.5f} within 1 half-ulp, worst {int(d.max())} ulp")
-    assert exact >= 0.97 and within1 >= 0.995 and d.max() <= 8
+    assert exact >= 0.998 and within1 >= 0.9998 and d.max() <= 8  # measured 0.9992 / 0.99993 / 5 (profiles/r2_parity_headline.txt)
     # masks: identical scores -> identical masks (bit-exact), HIP scores -> Hamming distance
     v_ref, t_ref = orc.threshold(ref, 0.3)
     hip_scores = [s.clone() for s in kv.score]
@@ -70,7 +70,7 @@ def test_config_c1_qwen05b_full_context():
     v_hip, _ = orc.threshold([s.cpu() for s in hip_scores], 0.3)
     ham = float((v_hip != v_ref).float().mean())
     print(f"C1 end-to-end mask Hamming distance: {ham:.2e}")
-    assert ham <= 2e-3
+    assert ham <= 1e-4  # measured 0 of 98 304
     # compaction == oracle prepare_init on the same mask
     fk, fv, lens, cus, mxs = orc.prepare_init(K, V, v_ref, sink)
     for l in range(L):

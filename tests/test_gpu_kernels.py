@@ -489,7 +489,7 @@ def test_score_then_select_end_to_end_hamming():
     v_hip, _, _, _ = ops().select_threshold(got, 0.3)
     ham = float((v_ref != v_hip.cpu()).float().mean())
     print(f"end-to-end mask Hamming distance: {ham:.2e}")
-    assert ham <= 5e-3
+    assert ham <= 1e-3  # measured 0 of 1024 on MI355X (gpurun call r2c23); one flipped entry is allowed
     # and the contract that matters: on the ORACLE's scores the HIP mask is bit-exact
     v_hip2, _, _, _ = ops().select_threshold(want.to(DEV), 0.3)
     assert torch.equal(v_hip2.cpu(), v_ref)
@@ -514,14 +514,15 @@ def test_score_chunk_headline_shape_parity_distribution(dtype):
     ham = float((v_ref != v_hip).float().mean())
     print(f"headline shape {dtype}: {exact:.5f} bit-identical, {within1:.5f} within 1 half-ulp, worst {worst}, "
           f"mask Hamming @0.3 {ham:.2e} of {d.numel()} scores")
-    assert exact >= HEADLINE_EXACT[dtype] and within1 >= 0.999 and worst <= 4
+    assert exact >= HEADLINE_EXACT[dtype] and within1 >= 0.9997 and worst <= 4
     assert ham <= HEADLINE_HAMMING[dtype]
 
 
-# measured on MI355X (profiles/r2_parity_headline.txt); the bounds are the measured values with a margin of 2x on the
-# non-identical fraction / Hamming distance
-HEADLINE_EXACT = {torch.float16: 0.97, torch.bfloat16: 0.97}
-HEADLINE_HAMMING = {torch.float16: 5e-3, torch.bfloat16: 5e-3}
+# measured on MI355X with the round-2 kernels (profiles/r2_parity_headline.txt): fp16 99.937 % bit-identical / 99.988 % within one
+# half-ulp / worst 2, bf16 99.988 % / 100 % / worst 1, mask Hamming distance 0 of 8000 for both.  The bounds are the measured
+# non-identical fractions with a margin of 2x; the Hamming bound allows two flipped entries.
+HEADLINE_EXACT = {torch.float16: 0.9987, torch.bfloat16: 0.99975}
+HEADLINE_HAMMING = {torch.float16: 2.5e-4, torch.bfloat16: 2.5e-4}
 
 
 # ------------------------------------------------------------------------------------------------
