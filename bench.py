@@ -242,7 +242,7 @@ def main(argv=None):
     ranks = Ranks(args.gpus, "nccl", dev)
     rank, world = ranks.rank, ranks.world
 
-    from kvzip_amd import _lib
+    from kvzip_amd import _lib, ops
     from kvzip_amd.kvcache import EvictCache
     lib = _lib.load()
 
@@ -382,6 +382,39 @@ def main(argv=None):
     len_k_host = kv.info["len_k_host"]
     kv.slice(seen)
 
+    # ---- the same attention call on an AdaKV-style RAGGED layer (head lengths 39 k / 4 k / 120 k / 500 ...): work items are cut
+    # from the sum of the lengths, so the GPU fills the same way --------------------------------
+    ragged = None
+    if rank == 0 and T > 0:
+        base = [39000, 4000, 120000, 500]
+        lens_r = [base[h % 4] for h in range(Hkv)]
+        starts_r, acc = [], 0
+        for n_ in lens_r:
+            starts_r.append(acc)
+            acc += n_ + 1024
+        kr_, vr_ = randn(acc, D), randn(acc, D)
+        qr_ = randn(Hkv, H // Hkv, D)
+        ks_ = torch.tensor(starts_r, dtype=torch.int32, device=dev)
+        kl_ = torch.tensor(lens_r, dtype=torch.int32, device=dev)
+        ws_ = ops.attn_workspace(Hkv, H // Hkv, 1, D, dev)
+        meta_ = ops._meta_host(starts_r, lens_r, Hkv)
+        for _ in range(3):
+            ops.varlen_attn(qr_, kr_, vr_, ks_, kl_, 1, max(lens_r), workspace=ws_, meta_host=meta_)
+        torch.cuda.synchronize()
+        lib.kvz_prof_reset()
+        lib.kvz_prof_enable(1)
+        for _ in range(50):
+            ops.varlen_attn(qr_, kr_, vr_, ks_, kl_, 1, max(lens_r), workspace=ws_, meta_host=meta_)
+        torch.cuda.synchronize()
+        lib.kvz_prof_enable(0)
+        r_ms, r_n = prof_read(lib, "varlen_attn")
+        r_bytes = 2.0 * sum(lens_r) * D * 2
+        if r_n:
+            ragged = {"bound": "hbm", "achieved": r_bytes / (r_ms / r_n / 1e3) / 1e9, "unit": "GB/s",
+                      "frac": r_bytes / (r_ms / r_n / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_ms": r_ms / r_n, "launches": r_n,
+                      "algorithmic_bytes": r_bytes, "head_lengths": lens_r}
+        del kr_, vr_
+
     if rank != 0:
         ranks.close()
         return
@@ -423,6 +456,8 @@ def main(argv=None):
                                "algorithmic_bytes": decode_bytes / L,
                                "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes")},
     }
+    if ragged is not None:
+        stages["decode_varlen_attn_ragged"] = ragged
     if head_level:
         h_ms, h_n = prof["select_heads"]
         stages["select_heads"] = {"bound": "launch", "avg_ms": h_ms / h_n if h_n else None, "launches": h_n,
@@ -483,6 +518,7 @@ def main(argv=None):
                            "kvzip_amd.dist.gather_results inside the timed region",
             "gathered_contexts": len(records),
             "score_streams": max(1, args.score_streams),
+            "score_streams_distinct": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,
         },
         "roofline": roofline,

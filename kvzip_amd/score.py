@@ -31,8 +31,8 @@ from . import ops
 _SIDE_STREAMS = {}
 
 
-def _overlaps(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 400_000) -> bool:
-    """True if spin kernels on the two streams run concurrently (wall time well below twice one kernel)."""
+def _spin_time(streams, cycles: int = 400_000) -> float:
+    """Wall time (ms) of one spin kernel per stream, launched together."""
     def timed(streams):
         torch.cuda.synchronize()
         t0 = torch.cuda.Event(enable_timing=True)
@@ -47,11 +47,24 @@ def _overlaps(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 400_
         t1.record()
         torch.cuda.synchronize()
         return t0.elapsed_time(t1)
-    timed([a])  # warm-up (first launch on a stream creates its queue)
-    timed([b])
-    one = min(timed([a]), timed([b]))
-    both = timed([a, b])
+    return timed(streams)
+
+
+def _overlaps(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+    """True if spin kernels on the two streams run concurrently (wall time well below twice one kernel)."""
+    _spin_time([a])  # warm-up (first launch on a stream creates its queue)
+    _spin_time([b])
+    one = min(_spin_time([a]), _spin_time([b]))
+    both = _spin_time([a, b])
     return both < 1.5 * one
+
+
+def _all_overlap(streams) -> bool:
+    """True if spin kernels on ALL the streams run at the same time (pairwise overlap does not prove it)."""
+    if len(streams) < 2:
+        return True
+    one = min(_spin_time([st]) for st in streams)
+    return min(_spin_time(streams), _spin_time(streams)) < 1.5 * one
 
 
 def _side_streams(device, n: int):
@@ -70,6 +83,8 @@ def _side_streams(device, n: int):
                     chosen.append(c)
                 if len(chosen) >= n:
                     break
+            while len(chosen) > 2 and not _all_overlap(chosen):  # three-way concurrency has to be seen, not inferred
+                chosen.pop()
         except Exception:  # no spin kernel in this build: take the candidates as they come
             chosen = cands[:n]
         while len(chosen) < n:  # fewer independent queues than requested: the extra streams simply do not overlap
