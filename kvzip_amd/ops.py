@@ -33,7 +33,19 @@ def _stream(t: torch.Tensor) -> int:
         raise KvzError("the HIP path needs device tensors (no CPU fallback)")
     if t.device.index != torch.cuda.current_device():
         torch.cuda.set_device(t.device)
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return raw_stream(t.device.index)
+
+
+try:  # the raw handle of the current stream without building a torch.cuda.Stream object (4 us -> 0.3 us per launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    _raw_stream = None
+
+
+def raw_stream(device_index: int) -> int:
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def _same_device(*tensors) -> None:

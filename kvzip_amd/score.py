@@ -138,8 +138,9 @@ class KVScore:
         if not self._pending or self._async < 0:
             return
         lib = ops._lib.load()
-        ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx,
-                                     torch.cuda.current_stream(self.device).cuda_stream), "kvz_async_wait")
+        dev = torch.device(self.device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx, ops.raw_stream(idx)), "kvz_async_wait")
         if layer_idx is None:
             self._pending = False
 
@@ -217,7 +218,7 @@ class KVScore:
             self._async = lib.kvz_async_create(self.n_layers)
             if self._async < 0:
                 ops.check(self._async, "kvz_async_create")
-        cur = torch.cuda.current_stream(dev).cuda_stream
+        cur = ops.raw_stream(dev.index)
         if nstreams == 1:
             self._wait_score()  # the caller's stream: everything before it is ordered anyway, later calls wait for it
             side = cur
