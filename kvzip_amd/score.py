@@ -74,8 +74,9 @@ def _side_streams(device, n: int):
     if pool is not None and len(pool) >= n:
         return pool[:n]
     with torch.cuda.device(key):
-        cands = [torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1)]
-        cands += [torch.cuda.Stream(device=dev) for _ in range(4)]
+        # candidates of NORMAL priority (measured: two high-priority streams among the three cost 1-4 % in bench.py - kernels on
+        # the remaining normal-priority stream fall behind and the caller's stream then waits for that layer's previous call)
+        cands = [torch.cuda.Stream(device=dev) for _ in range(6)]
         chosen = []
         try:
             for c in cands:
