@@ -94,6 +94,21 @@ int kvz_score_chunk_async(int handle, int slot, kvz_stream_t caller, kvz_stream_
                           void* out, int64_t out_head_stride,
                           void* ws, size_t ws_bytes);
 
+/* The same call with the row slices of pass B merged by atomics into a LOG buffer and no finalize launch: `log_out` is
+ * [Hkv, log_head_stride] uint32 = bit patterns of the fp32 log-scores  max_r (x - m_r - log l_r)  (<= 0, so the maximum is an
+ * unsigned minimum of the patterns), pre-filled with kvz_score_log_fill (-inf).  kvz_score_finalize_log turns a whole buffer
+ * (all layers, all chunks) into the 16-bit scores of  attention/score.py:59-63  at once; entries never scored leave `out`
+ * untouched.  Same values as kvz_score_chunk, one launch less per (layer, chunk). */
+int kvz_score_chunk_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                        int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
+                        uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, kvz_stream_t stream);
+int kvz_score_chunk_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
+                              const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                              int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
+                              uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
+int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream);
+int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream);
+
 /* Test hook for the rounding chain of a1: out[i] = half( float(in[i]) / float(sqrt(D)) ) computed exactly as the
  * scoring kernels do (exact-reciprocal multiply when the host's exhaustive search found one, IEEE division
  * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */

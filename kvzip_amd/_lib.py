@@ -30,6 +30,11 @@ SIGNATURES = {
     "kvz_async_destroy": (_i, [_i]),
     "kvz_async_wait": (_i, [_i, _i, _vp]),
     "kvz_score_chunk_async": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz]),
+    "kvz_score_chunk_log": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "kvz_score_chunk_async_log": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp,
+                                       _sz]),
+    "kvz_score_log_fill": (_i, [_vp, _i64, _vp]),
+    "kvz_score_finalize_log": (_i, [_vp, _i64, _vp, _i, _vp]),
     "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_select_workspace_bytes": (_sz, []),

@@ -177,10 +177,30 @@ extern "C" int kvz_async_wait(int handle, int slot, kvz_stream_t stream) {
         }
     return KVZ_OK;
 }
+static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
+                                  int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                                  int end, int q_len, int Hkv, int G, int D, int dtype, void* out, int64_t out_head_stride,
+                                  void* ws, size_t ws_bytes, bool log);
+
 extern "C" int kvz_score_chunk_async(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
                                      int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
                                      int end, int q_len, int Hkv, int G, int D, int dtype, void* out, int64_t out_head_stride,
                                      void* ws, size_t ws_bytes) {
+    return score_chunk_async_impl(handle, slot, caller, side, q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G,
+                                  D, dtype, out, out_head_stride, ws, ws_bytes, false);
+}
+extern "C" int kvz_score_chunk_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
+                                         int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                                         int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out,
+                                         int64_t log_head_stride, void* ws, size_t ws_bytes) {
+    return score_chunk_async_impl(handle, slot, caller, side, q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G,
+                                  D, dtype, log_out, log_head_stride, ws, ws_bytes, true);
+}
+
+static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
+                                  int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                                  int end, int q_len, int Hkv, int G, int D, int dtype, void* out, int64_t out_head_stride,
+                                  void* ws, size_t ws_bytes, bool log) {
     kvz::AsyncCtx* c = kvz::async_get(handle);
     KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_chunk_async: bad handle %d", handle);
     KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_chunk_async: bad slot %d", slot);
@@ -191,8 +211,10 @@ extern "C" int kvz_score_chunk_async(int handle, int slot, kvz_stream_t caller, 
             return KVZ_ELAUNCH;
         }
     }
-    const int rc = kvz_score_chunk(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, out,
-                                   out_head_stride, ws, ws_bytes, side);
+    const int rc = log ? kvz_score_chunk_log(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype,
+                                             reinterpret_cast<uint32_t*>(out), out_head_stride, ws, ws_bytes, side)
+                       : kvz_score_chunk(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, out,
+                                         out_head_stride, ws, ws_bytes, side);
     if (rc != KVZ_OK) return rc;
     if (side != caller) {
         if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {

@@ -107,6 +107,8 @@ struct ScoreArgs {
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
     FastDiv dq, dh, dz;  // q_len, Hkv, work items per key slice of pass A
+    uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
+    int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
 };
 
 // reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
@@ -1850,11 +1852,22 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
         best[i] = b;
     }
     if (l31 == 0) {
-        float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+        if (a.log_out) {
+            // log-softmax values are <= 0 (clamped: rounding may leave +1e-7, and exp of either rounds to the same 16-bit 1.0), and
+            // for non-positive floats "larger" is "smaller bit pattern": the maximum over the row slices is an unsigned minimum
+            uint32_t* dst = a.log_out + (int64_t)h * a.log_head_stride;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (j < a.m) dst[j] = best[i];
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (j < a.m) atomicMin(dst + j, __builtin_bit_cast(uint32_t, fminf(best[i], 0.f)) | 0u);
+            }
+        } else {
+            float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (j < a.m) dst[j] = best[i];
+            }
         }
     }
 }
@@ -1868,6 +1881,16 @@ __global__ void score_finalize_kernel(const float* __restrict__ colpart, int spl
     float t = -INFINITY;
     for (int s = 0; s < splits; ++s) t = fmaxf(t, colpart[((int64_t)s * Hkv + h) * m + j]);
     out[(int64_t)h * out_head_stride + j] = (T)expf(t);
+}
+
+// log buffer -> scores: entries still holding the fill pattern (-inf: never scored) leave `out` untouched
+constexpr uint32_t SC_LOG_EMPTY = 0xFF800000u;
+template <typename T>
+__global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int64_t n, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = log[i];
+    if (b != SC_LOG_EMPTY) out[i] = (T)expf(__builtin_bit_cast(float, b));
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -2024,6 +2047,7 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
 #endif
     }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
+    if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
                        a.row_splits, Hkv, a.m, reinterpret_cast<T*>(a.out), a.out_head_stride);
     KVZ_CHECK_LAUNCH("score_finalize_kernel");
@@ -2058,11 +2082,55 @@ extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, in
     return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m);
 }
 
+static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                            int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
+                            int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
+                            kvz_stream_t stream_);
+
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                                int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                                int64_t out_head_stride, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    KVZ_REQUIRE(out, KVZ_EINVAL, "kvz_score_chunk: null pointer");
+    return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, out, out_head_stride,
+                            nullptr, 0, ws, ws_bytes, stream_);
+}
+
+extern "C" int kvz_score_chunk_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                                   int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out,
+                                   int64_t log_head_stride, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_chunk_log: bad log buffer");
+    return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
+                            log_head_stride, ws, ws_bytes, stream_);
+}
+
+extern "C" int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream_) {
+    KVZ_REQUIRE(log && n >= 0, KVZ_EINVAL, "kvz_score_log_fill: bad arguments");
+    if (n == 0) return KVZ_OK;
+    KVZ_REQUIRE(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(log), (int)SC_LOG_EMPTY, (size_t)n, (hipStream_t)stream_) == hipSuccess,
+                KVZ_ELAUNCH, "kvz_score_log_fill: hipMemsetD32Async failed");
+    return KVZ_OK;
+}
+
+extern "C" int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream_) {
+    KVZ_REQUIRE(log && out && n >= 0, KVZ_EINVAL, "kvz_score_finalize_log: bad arguments");
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_score_finalize_log: bad dtype %d", dtype);
+    if (n == 0) return KVZ_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    KVZ_REQUIRE(q && k && out && ws, KVZ_EINVAL, "kvz_score_chunk: null pointer");
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    ProfScope ps("score_finalize_log", stream);
+    if (dtype == KVZ_F16) hipLaunchKernelGGL((score_finalize_log_kernel<_Float16>), grid, block, 0, stream, log, n, reinterpret_cast<_Float16*>(out));
+    else hipLaunchKernelGGL((score_finalize_log_kernel<__bf16>), grid, block, 0, stream, log, n, reinterpret_cast<__bf16*>(out));
+    KVZ_CHECK_LAUNCH("score_finalize_log_kernel");
+    return KVZ_OK;
+}
+
+static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                            int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
+                            int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
+                            kvz_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(q && k && (out || log_out) && ws, KVZ_EINVAL, "kvz_score_chunk: null pointer");
+    KVZ_REQUIRE(log_out == nullptr || KVZ_PB_V2, KVZ_EUNSUPPORTED, "kvz_score_chunk_log: this build uses the round-1 column kernel");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
     KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_score_chunk: head_dim %d unsupported (64 or 128)", D);
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_score_chunk: bad dtype %d", dtype);
@@ -2084,6 +2152,7 @@ extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void*
     a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
+    a.log_out = log_out; a.log_head_stride = log_head_stride;
     a.dq = make_fastdiv(q_len);
     a.dh = make_fastdiv(Hkv);
     a.dz = make_fastdiv((G * q_len + PA_ROWS - 1) / PA_ROWS * Hkv);

@@ -121,7 +121,7 @@ class _CacheBase(KVScore):
     def adopt_dense(self, store_k: List[torch.Tensor], store_v: List[torch.Tensor], filled: int):
         """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
         serving engine prefilled elsewhere); ``filled`` rows are in use."""
-        self._wait_score()  # scoring calls still in flight read the storage that is being replaced
+        self._wait_score(finalize=False)  # scoring calls still in flight read the storage that is being replaced
         self._views.clear()
         self._store_k, self._store_v = list(store_k), list(store_v)
         self._fill = [filled for _ in store_k]
@@ -139,7 +139,7 @@ class _CacheBase(KVScore):
         # asynchronous scoring reads the cache storage, the score buffer and the workspaces from side streams: order the
         # current stream behind it before the caching allocator may hand that memory to somebody else
         try:
-            self._wait_score()
+            self._wait_score(finalize=False)
         except Exception:
             pass
         self._release_async()

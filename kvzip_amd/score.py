@@ -117,6 +117,9 @@ class KVScore:
         self._score_side: List["torch.cuda.Stream"] = []
         self._async = -1               # handle of the library's asynchronous-scoring context (events per layer)
         self._pending = False          # scoring calls may still be in flight on a side stream
+        self.score_deferred = True     # row slices merged by atomics into a log buffer, ONE finalize launch when the scores are read
+        self._score_log: Optional[torch.Tensor] = None   # [L, 1, Hkv, N] int32: bit patterns of the fp32 log-scores (-inf = empty)
+        self._log_dirty = False
 
     # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
     @property
@@ -134,16 +137,34 @@ class KVScore:
     def score(self, value):
         self._score = value
 
-    def _wait_score(self, layer_idx: Optional[int] = None):
-        """Make the current stream wait for the scoring calls still in flight (of one layer, or of all)."""
-        if not self._pending or self._async < 0:
+    def _wait_score(self, layer_idx: Optional[int] = None, finalize: bool = True):
+        """Make the current stream wait for the scoring calls still in flight (of one layer, or of all).  Waiting for all of them
+        with ``finalize`` also turns the log buffer of the deferred path into the 16-bit scores (one launch for everything)."""
+        if self._pending and self._async >= 0:
+            lib = ops._lib.load()
+            dev = torch.device(self.device)
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx, ops.raw_stream(idx)), "kvz_async_wait")
+            if layer_idx is None:
+                self._pending = False
+        if layer_idx is None and finalize and self._log_dirty:
+            self._finalize_log()
+
+    def _finalize_log(self):
+        log, buf = self._score_log, self._score_buf
+        self._log_dirty = False
+        if log is None or buf is None or buf.numel() == 0:
             return
         lib = ops._lib.load()
-        dev = torch.device(self.device)
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx, ops.raw_stream(idx)), "kvz_async_wait")
-        if layer_idx is None:
-            self._pending = False
+        rc = lib.kvz_score_finalize_log(log.data_ptr(), log.numel(), buf.data_ptr(), ops._dtype_code(buf.dtype), ops._stream(buf))
+        ops.check(rc, "kvz_score_finalize_log")
+
+    def _new_score_log(self, n: int) -> Optional[torch.Tensor]:
+        if not self.score_deferred or n == 0 or not torch.device(self.device).type == "cuda":
+            return None
+        log = torch.empty((self.n_layers, 1, self.n_heads_kv, n), dtype=torch.int32, device=self.device)
+        ops.check(ops._lib.load().kvz_score_log_fill(log.data_ptr(), log.numel(), ops._stream(log)), "kvz_score_log_fill")
+        return log
 
     def _release_async(self):
         if self._async >= 0:
@@ -158,8 +179,10 @@ class KVScore:
         self.get_score = True
         self.causal_mask_score = None
         n = int(self.ctx_len) if self.ctx_len is not None else 0
-        self._wait_score()
+        self._wait_score(finalize=False)
+        self._log_dirty = False
         self._score_buf = torch.empty((self.n_layers, 1, self.n_heads_kv, n), dtype=self.dtype, device=self.device)
+        self._score_log = self._new_score_log(n)
         self._score_fill = [0 for _ in range(self.n_layers)]
         self._score = None
 
@@ -176,12 +199,13 @@ class KVScore:
     def _ensure_score_capacity(self, need: int):
         if self._score_buf.shape[-1] >= need:
             return
-        self._wait_score()
+        self._wait_score()  # (finalizes what the log buffer holds: the old scores move as 16-bit values)
         new = torch.empty((self.n_layers, 1, self.n_heads_kv, need), dtype=self.dtype, device=self.device)
         old = self._score_buf.shape[-1]
         if old:
             new[..., :old].copy_(self._score_buf)
         self._score_buf = new
+        self._score_log = self._new_score_log(need)
 
     # reference: attention/score.py:36-65
     def _get_score(self, query_states: torch.Tensor, key_states: torch.Tensor, layer_idx: int):
@@ -213,7 +237,7 @@ class KVScore:
             self._score_ws.append(None)
         ws = self._score_ws[slot]
         if ws is None or ws.numel() < need:
-            self._wait_score()  # (the old workspace of this slot may still be in use)
+            self._wait_score(finalize=False)  # (the old workspace of this slot may still be in use)
             ws = self._score_ws[slot] = torch.empty(need, dtype=torch.uint8, device=dev)
         if self._async < 0:
             self._async = lib.kvz_async_create(self.n_layers)
@@ -221,7 +245,7 @@ class KVScore:
                 ops.check(self._async, "kvz_async_create")
         cur = ops.raw_stream(dev.index)
         if nstreams == 1:
-            self._wait_score()  # the caller's stream: everything before it is ordered anyway, later calls wait for it
+            self._wait_score(finalize=False)  # the caller's stream: everything before it is ordered anyway, later calls wait for it
             side = cur
         else:
             if len(self._score_side) < nstreams:
@@ -232,11 +256,22 @@ class KVScore:
             # (key_states is a view of the cache storage, which is only reallocated after _wait_score)
             self._pending = True
         n_tot = buf.shape[-1]
-        out_ptr = buf.data_ptr() + (layer_idx * Hkv * n_tot + f) * buf.element_size()
-        rc = lib.kvz_score_chunk_async(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
-                                       key_states.data_ptr(), key_states.stride(1), klen, self.sink, self.start_idx,
-                                       self.end_idx, q_len, Hkv, H // Hkv, D, ops._dtype_code(query_states.dtype), out_ptr, n_tot,
-                                       ws.data_ptr(), ws.numel())
+        log = self._score_log
+        if log is not None and log.shape[-1] == n_tot:
+            # deferred path: pass B merges its row slices by atomics into the log buffer, the finalize launch happens once, when
+            # the scores are read (3 launches per call instead of 4)
+            out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
+            rc = lib.kvz_score_chunk_async_log(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
+                                               key_states.data_ptr(), key_states.stride(1), klen, self.sink, self.start_idx,
+                                               self.end_idx, q_len, Hkv, H // Hkv, D, ops._dtype_code(query_states.dtype), out_ptr,
+                                               n_tot, ws.data_ptr(), ws.numel())
+            self._log_dirty = True
+        else:
+            out_ptr = buf.data_ptr() + (layer_idx * Hkv * n_tot + f) * buf.element_size()
+            rc = lib.kvz_score_chunk_async(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
+                                           key_states.data_ptr(), key_states.stride(1), klen, self.sink, self.start_idx,
+                                           self.end_idx, q_len, Hkv, H // Hkv, D, ops._dtype_code(query_states.dtype), out_ptr, n_tot,
+                                           ws.data_ptr(), ws.numel())
         ops.check(rc, "kvz_score_chunk_async")
         self._score_fill[layer_idx] = f + m
 

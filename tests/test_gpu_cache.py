@@ -205,9 +205,10 @@ def test_async_scoring_equals_single_stream():
     q_in = [[torch.randn(1, H, (en - st) + 9, D, generator=g, device=DEV).half() for _ in range(L)] for st, en in chunks]
     k_in = [[torch.randn(1, Hkv, (en - st) + 9, D, generator=g, device=DEV).half() for _ in range(L)] for st, en in chunks]
 
-    def run(nstreams):
+    def run(nstreams, deferred=True):
         kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=torch.float16, verbose=False)
         kv.n_score_streams = nstreams
+        kv.score_deferred = deferred
         for l in range(L):
             kv.update(K[l], V[l], l)
         kv.init_score()
@@ -224,10 +225,53 @@ def test_async_scoring_equals_single_stream():
         return score, thres, kv.valid.clone()
 
     s1, t1, v1 = run(1)
-    for _ in range(3):
-        s2, t2, v2 = run(2)
+    for n in (2, 3, 3):
+        s2, t2, v2 = run(n)
         assert torch.equal(s1.view(torch.int16), s2.view(torch.int16))
         assert t1 == t2 and torch.equal(v1, v2)
+    # deferred finalize (row slices of pass B merged by atomics into a log buffer, ONE finalize launch when .score is read)
+    # against the direct path (finalize launch per call): the same bits
+    for n in (1, 3):
+        s3, t3, v3 = run(n, deferred=False)
+        assert torch.equal(s1.view(torch.int16), s3.view(torch.int16))
+        assert t1 == t3 and torch.equal(v1, v3)
+
+
+def test_deferred_scores_and_external_blocks():
+    """The deferred path next to the reference's ``_update_score`` (externally computed blocks written straight into the score
+    buffer), a buffer that has to grow, and ``.score`` read between chunks: every block must come out as the direct kernel call
+    (``ops.score_chunk``) produces it."""
+    from kvzip_amd import ops
+    from kvzip_amd.kvcache import EvictCache
+    L, H, Hkv, D, sink, N, chunk = 2, 8, 2, 128, 8, 1024, 256
+    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    K = [torch.randn(1, Hkv, sink + N, D, generator=g, device=DEV).half() for _ in range(L)]
+    kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=torch.float16, verbose=False)
+    for l in range(L):
+        kv.update(K[l], K[l], l)
+    kv.ctx_len = N // 2           # too small on purpose: the buffers have to grow once
+    kv.init_score()
+    want = [[] for _ in range(L)]
+    for c, st in enumerate(range(sink, sink + N, chunk)):
+        en = st + chunk
+        kv.start_idx, kv.end_idx = st, en
+        seen = kv._seen_tokens
+        for l in range(L):
+            q = torch.randn(1, H, chunk + 7, D, generator=g, device=DEV).half()
+            kr = torch.randn(1, Hkv, chunk + 7, D, generator=g, device=DEV).half()
+            k_all, _ = kv.update(kr, kr, l)
+            direct = ops.score_chunk(q, k_all, sink, st, en)
+            want[l].append(direct)
+            if c == 1 and l == 0:
+                kv._update_score(l, direct)      # an externally computed block
+            else:
+                kv._get_score(q, k_all, l)
+        kv.slice(seen)
+        if c == 2:
+            _ = kv.score                          # a read in the middle finalizes what is there; scoring goes on afterwards
+    for l in range(L):
+        assert torch.equal(kv.score[l].view(torch.int16), torch.cat(want[l], dim=-1).view(torch.int16)), l
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
