@@ -65,9 +65,10 @@ constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget i
 #ifndef KVZ_KSPLIT_TILES
 #define KVZ_KSPLIT_TILES 8
 #endif
-// pass A: key tiles per work item.  Alone on the GPU 4 is fastest (8: +5 %, the tail of unevenly loaded blocks), but in the
-// scoring loop the calls of consecutive layers overlap and the tail is filled by the next kernel: there the WORK counts, and 8
-// halves the item switches (~3 000 cycles each, all eight waves): +6.5 % tokens/s in bench.py (16 and 32: +5 %).
+// pass A with the snake schedule (KVZ_PA_PLAN=0): key tiles per work item.  Alone on the GPU 4 is fastest (8: +5 %, the tail of
+// unevenly loaded blocks), but in the scoring loop the calls of consecutive layers overlap and the tail is filled by the next
+// kernel: there the WORK counts, and 8 halves the item switches (~3 000 cycles each, all eight waves): +6.5 % tokens/s in
+// bench.py (16 and 32: +5 %).  The balanced partition (KVZ_PA_PLAN=1, default) has neither the tail nor the extra switches.
 constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;
 constexpr int SC_PERSISTENT_BLOCKS = 256;          // pass A: one persistent block per CU
 
@@ -387,6 +388,9 @@ constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
 #ifndef KVZ_PA_V3
 #define KVZ_PA_V3 0                             // 1: 64 rows per wave + exactly balanced static partition (kvz_score_pa3.h): measured
 #endif                                          // -2 % at D = 64, does not fit the register file at D = 128 - off
+#ifndef KVZ_PA_PLAN
+#define KVZ_PA_PLAN 1                           // 1: exactly balanced static partition (PaPlan) instead of the snake schedule of key slices
+#endif
 #ifndef KVZ_PA_V2
 #define KVZ_PA_V2 1                             // 1: software-pipelined row-statistics kernel (round 2); 0: round-1 kernel
 #endif
@@ -902,6 +906,107 @@ template <typename T> __device__ static inline float max_packed16(const uint32_t
 constexpr float PA2_SUM_LIMIT = 65536.f;
 constexpr float PA2_SUM_LOW = 9.5367431640625e-07f;  // 2^-20: lower bound for the FIRST block of an item (reference still 0)
 
+// ---- static, exactly balanced partition of pass A (round 2) --------------------------------------------------------------
+// The (row tile, head, key tile) space is laid out as ONE sequence of key tiles - units u = rt * Hkv + h in order, each with the
+// key tiles up to the causal limit of its last row - and cut into equal ranges, one per persistent block.  A block walks its
+// range as segments (= consecutive key tiles of one unit); a unit's statistics come out as one partial per block that touched
+// it (slot = ordinal of the block inside the unit).  Built on the host per launch (a few hundred integer operations) and passed
+// BY VALUE: no index arithmetic with divisions in the kernel, no tail of unevenly loaded blocks.
+constexpr int PLAN_MAX_BLOCKS = 256;
+struct PaPlan {
+    uint16_t unit[PLAN_MAX_BLOCKS + 1];  // block b starts at key tile tile[b] of unit unit[b] and ends where block b+1 starts
+    uint16_t tile[PLAN_MAX_BLOCKS + 1];
+    int nb;                              // blocks
+    int max_seg;                         // most blocks that touch one unit (= partial statistics per row)
+};
+// key tiles of row tile rt (rows rt*rows .. +rows): up to the causal limit of its last row (virtual keys sink ++ ctx ++ repeat)
+__host__ __device__ static inline int plan_ntiles(int rt, int rows, int R, int q_len, int sink, int m) {
+    const int r0 = rt * rows, r1 = (R - 1 < r0 + rows - 1) ? R - 1 : r0 + rows - 1;
+    const int qmax = (r0 / q_len == r1 / q_len) ? (r1 % q_len) : (q_len - 1);
+    return (sink + m + qmax + 1 + SC_TILE - 1) / SC_TILE;
+}
+#ifndef KVZ_PLAN_SWITCH_Q   // cost model of the partition, in quarter key tiles: entering a unit (query rows, first chain,
+#define KVZ_PLAN_SWITCH_Q 0  // bookkeeping) and a key tile that reaches into the causal zone of the unit's rows (the block waits for
+#endif                       // the waves that run the masked epilogue: 1.45 x); a plain tile costs 4
+#ifndef KVZ_PLAN_MASKED_Q
+#define KVZ_PLAN_MASKED_Q 6  // (4 / 6 / 8 and a switch cost of 0 / 4 / 6 / 12 measured: within 1 % of each other, 6 / 0 best)
+#endif
+// does key tile t hold the causal limit of some row of row tile rt?  (those rows' wave runs the masked epilogue there and the
+// other waves of the block wait for it at the hand-over)  The rows of a row tile are one or two runs of consecutive positions.
+static inline bool plan_tile_masked(int rt, int t, int rows, int R, int q_len, int sink, int m) {
+    const int r0 = rt * rows, r1 = (R - 1 < r0 + rows - 1) ? R - 1 : r0 + rows - 1;
+    const int lo = t * SC_TILE, hi = lo + SC_TILE - 1;  // a row with limit L has tile t partially hidden iff lo <= L < hi
+    auto hit = [&](int qa, int qb) { const int La = sink + m + qa, Lb = sink + m + qb; return La < hi && Lb >= lo; };
+    if (r0 / q_len == r1 / q_len) return hit(r0 % q_len, r1 % q_len);
+    return hit(r0 % q_len, q_len - 1) || hit(0, r1 % q_len) || (r1 / q_len - r0 / q_len > 1);
+}
+static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, int Hkv) {
+    const int R = G * q_len, RT = (R + rows - 1) / rows;
+    const int64_t U = (int64_t)RT * Hkv;
+    if (U > 65535 || (sink + m + q_len) / SC_TILE + 1 > 65535) return false;
+    constexpr int SW = KVZ_PLAN_SWITCH_Q, MQ = KVZ_PLAN_MASKED_Q;
+    // cost of the first t tiles of row tile rt (entering included)
+    auto cost = [&](int rt, int t) -> int64_t {
+        int64_t c = SW;
+        for (int i = 0; i < t; ++i) c += plan_tile_masked(rt, i, rows, R, q_len, sink, m) ? MQ : 4;
+        return c;
+    };
+    // inverse: the smallest t with cost(rt, t) >= c
+    auto tile_at = [&](int rt, int64_t c) -> int {
+        int64_t acc = SW;
+        int t = 0;
+        while (acc < c) { acc += plan_tile_masked(rt, t, rows, R, q_len, sink, m) ? MQ : 4; ++t; }
+        return t;
+    };
+    int64_t W = 0, tiles = 0;
+    for (int rt = 0; rt < RT; ++rt) {
+        const int nt = plan_ntiles(rt, rows, R, q_len, sink, m);
+        W += cost(rt, nt) * Hkv;
+        tiles += (int64_t)nt * Hkv;
+    }
+    p.nb = (int)(tiles < PLAN_MAX_BLOCKS ? tiles : PLAN_MAX_BLOCKS);
+    // cut b in absolute tile index: from the cost axis, then clamped so that every block keeps at least one tile
+    int u = 0;
+    int64_t cbefore = 0, tbefore = 0;  // cost / tiles of the units before u
+    int nt = plan_ntiles(0, rows, R, q_len, sink, m);
+    int64_t cu = cost(0, nt);
+    int64_t prev = -1;
+    int wu = 0;           // unit that holds absolute tile index `g` (second cursor, for the conversion back)
+    int64_t wbefore = 0;
+    int wnt = nt;
+    for (int b = 0; b <= p.nb; ++b) {
+        const int64_t target = W * b / p.nb;
+        while (u < U && cbefore + cu <= target) {
+            cbefore += cu;
+            tbefore += nt;
+            ++u;
+            if (u < U) { nt = plan_ntiles(u / Hkv, rows, R, q_len, sink, m); cu = cost(u / Hkv, nt); }
+        }
+        int64_t g = tbefore + ((u < U) ? tile_at(u / Hkv, target - cbefore) : 0);
+        if (g <= prev) g = prev + 1;
+        if (g < b) g = b;
+        if (g > tiles - (p.nb - b)) g = tiles - (p.nb - b);
+        if (b == 0) g = 0;
+        prev = g;
+        while (wu < U && wbefore + wnt <= g) {
+            wbefore += wnt;
+            ++wu;
+            if (wu < U) wnt = plan_ntiles(wu / Hkv, rows, R, q_len, sink, m);
+        }
+        p.unit[b] = (uint16_t)wu;
+        p.tile[b] = (uint16_t)(g - wbefore);
+    }
+    for (int b = p.nb + 1; b <= PLAN_MAX_BLOCKS; ++b) { p.unit[b] = p.unit[p.nb]; p.tile[b] = p.tile[p.nb]; }
+    int best = 1, run = 1;  // most blocks per unit: a run of block starts inside one unit (+ the block that opened it)
+    for (int b = 1; b < p.nb; ++b) {
+        if (p.tile[b] > 0 && p.unit[b] == p.unit[b - 1]) ++run;
+        else run = (p.tile[b] > 0) ? 2 : 1;
+        if (run > best) best = run;
+    }
+    p.max_seg = best;
+    return true;
+}
+
 // optional in-kernel timeline (-DKVZ_TRACE=1, tools/trace2.py): s_memtime stamps of ONE block per 32, all 8 waves, 8 stamps per
 // tile = start of the four steps, arrival at / release from the hand-over barrier, end of the hand-over, end of the tile
 #ifndef KVZ_TRACE
@@ -919,7 +1024,7 @@ __device__ unsigned long long g_trace2[8 * 8 * 40 * 16];
 #endif  // a block whose exponentials (vs the reference) sum to more moves the reference
 
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a, PaPlan plan) {
     constexpr int NWAVES = PA_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
@@ -965,6 +1070,34 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL & 1
     bool abl_first = true;
 #endif
+#if KVZ_PA_PLAN
+    // exactly balanced static partition (PaPlan): this block's range of the tile sequence, walked as segments; Item.k = unit
+    const int u_first = plan.unit[blockIdx.x], t_first = plan.tile[blockIdx.x];
+    const int u_end = plan.unit[blockIdx.x + 1], t_end = plan.tile[blockIdx.x + 1];  // exclusive: (u_end, t_end)
+    int ord0 = 0;  // ordinal of the first segment inside its unit = earlier blocks that also started inside it (+ the opener)
+    if (t_first > 0) {
+        ord0 = 1;
+        for (int bb = (int)blockIdx.x - 1; bb > 0 && plan.unit[bb] == u_first && plan.tile[bb] > 0; --bb) ++ord0;
+    }
+    auto item_from = [&](int u) -> Item {
+        Item it;
+        it.k = u; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
+        if (u > u_end || (u == u_end && t_end == 0)) return it;
+        it.rt = a.dh.div(u);
+        it.h = u - it.rt * a.n_kv_heads;
+        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
+        const int h0 = a.dq.div(r0), h1 = a.dq.div(r1);
+        const int qmax = (h0 == h1) ? (r1 - h1 * a.q_len) : (a.q_len - 1);
+        const int ntiles = (a.sink + a.m + qmax + 1 + SC_TILE - 1) / SC_TILE;
+        it.t_lo = (u == u_first) ? t_first : 0;
+        it.t_hi = (u == u_end) ? t_end : ntiles;
+        it.z = (u == u_first) ? ord0 : 0;
+        return it;
+    };
+    const int first_item = u_first;
+    (void)decode; (void)nitems; (void)G_;
+#else
+    const int first_item = 0;
     auto item_from = [&](int k) -> Item {
         Item it;
         it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
@@ -979,6 +1112,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             }
         }
     };
+#endif
     auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
     // tiles (128 consecutive virtual keys) that lie inside ONE segment are consecutive rows of the cache: [tc_lo, tc_hi) inside
     // the ctx chunk, [tr_lo, tr_hi) inside the repeat chunk, [0, ts_hi) inside the sink; every other tile straddles a boundary
@@ -1095,7 +1229,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
 
-    Item cur = item_from(0);
+    Item cur = item_from(first_item);
     if (!valid(cur)) return;
     Item nxt = item_from(cur.k + 1);
     bool sq_in_next = false, sq_done = false;
@@ -2015,7 +2149,24 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         }
         KVZ_CHECK_LAUNCH("score_rowstat3_kernel");
         const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
-        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total);
+        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total, P3_ROWS);
+        KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
+    }
+#else
+#if KVZ_PA_V2 && KVZ_PA_PLAN
+    {
+        PaPlan plan;
+        if (!make_plan(plan, PA_ROWS, a.sink, a.m, a.q_len, a.G, Hkv)) {
+            set_error("kvz_score_chunk: more than 65535 (head, row tile) units");
+            return KVZ_EUNSUPPORTED;
+        }
+        {
+            ProfScope ps("score_rowstat", stream);
+            hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
+        }
+        KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
+        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
+        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total, PA_ROWS);
         KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
     }
 #else
@@ -2024,7 +2175,8 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         const int blocks = min(items, SC_PERSISTENT_BLOCKS);
         ProfScope ps("score_rowstat", stream);
 #if KVZ_PA_V2
-        hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
+        PaPlan plan{};
+        hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a, plan);
 #else
         hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
 #endif
@@ -2035,6 +2187,7 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, R, rows_total);
     }
     KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
+#endif
 #endif
     const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
@@ -2069,6 +2222,9 @@ static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sin
 #if KVZ_PA_V3
     PaPlan plan;  // one partial per block that touches a 512-row tile
     if (p3_make_plan(plan, sink, m, q_len, G, Hkv) && plan.max_seg > slices) slices = plan.max_seg;
+#elif KVZ_PA_V2 && KVZ_PA_PLAN
+    PaPlan plan;  // one partial per block that touches a row tile
+    if (make_plan(plan, PA_ROWS, sink, m, q_len, G, Hkv) && plan.max_seg > slices) slices = plan.max_seg;
 #endif
     return align256((size_t)slices * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
 }

@@ -18,54 +18,11 @@
 constexpr int P3_WAVES = 8;
 constexpr int P3_RG = 2;
 constexpr int P3_ROWS = P3_WAVES * P3_RG * 32;  // 512 query rows per row tile
-constexpr int P3_MAX_BLOCKS = 256;
+constexpr int P3_MAX_BLOCKS = PLAN_MAX_BLOCKS;
 
-struct PaPlan {
-    uint16_t unit[P3_MAX_BLOCKS + 1];  // block b starts at key tile tile[b] of unit unit[b] (unit = rt * Hkv + h) and ends where
-    uint16_t tile[P3_MAX_BLOCKS + 1];  // block b+1 starts
-    int nb;                            // blocks
-    int max_seg;                       // most blocks that touch one unit (= partial statistics per row)
-};
-
-// key tiles of row tile rt: up to the causal limit of its last row (virtual key sequence sink ++ ctx ++ repeat)
-__host__ __device__ static inline int p3_ntiles(int rt, int R, int q_len, int sink, int m) {
-    const int r0 = rt * P3_ROWS, r1 = (R - 1 < r0 + P3_ROWS - 1) ? R - 1 : r0 + P3_ROWS - 1;
-    const int qmax = (r0 / q_len == r1 / q_len) ? (r1 % q_len) : (q_len - 1);
-    return (sink + m + qmax + 1 + SC_TILE - 1) / SC_TILE;
-}
-
-static bool p3_make_plan(PaPlan& p, int sink, int m, int q_len, int G, int Hkv) {
-    const int R = G * q_len, RT = (R + P3_ROWS - 1) / P3_ROWS;
-    const int64_t U = (int64_t)RT * Hkv;
-    if (U > 65535) return false;
-    int64_t W = 0;
-    for (int rt = 0; rt < RT; ++rt) W += (int64_t)p3_ntiles(rt, R, q_len, sink, m) * Hkv;
-    if (p3_ntiles(RT - 1, R, q_len, sink, m) > 65535) return false;
-    p.nb = (int)(W < P3_MAX_BLOCKS ? W : P3_MAX_BLOCKS);
-    int u = 0;
-    int64_t before = 0;  // tiles of the units before u
-    int nt = p3_ntiles(0, R, q_len, sink, m);
-    for (int b = 0; b <= p.nb; ++b) {
-        const int64_t target = W * b / p.nb;
-        while (u < U && before + nt <= target) {
-            before += nt;
-            ++u;
-            if (u < U) nt = p3_ntiles(u / Hkv, R, q_len, sink, m);
-        }
-        p.unit[b] = (uint16_t)u;
-        p.tile[b] = (uint16_t)(target - before);
-    }
-    for (int b = p.nb + 1; b <= P3_MAX_BLOCKS; ++b) { p.unit[b] = p.unit[p.nb]; p.tile[b] = p.tile[p.nb]; }
-    // most blocks per unit: a run of block starts inside one unit
-    int best = 1, run = 1;
-    for (int b = 1; b < p.nb; ++b) {
-        if (p.tile[b] > 0 && p.unit[b] == p.unit[b - 1]) ++run;
-        else run = (p.tile[b] > 0) ? 2 : 1;
-        if (run > best) best = run;
-    }
-    p.max_seg = best;
-    return true;
-}
+// (PaPlan, plan_ntiles and make_plan live in kvz_score.hip: the 32-rows-per-wave kernel uses the same partition)
+__host__ __device__ static inline int p3_ntiles(int rt, int R, int q_len, int sink, int m) { return plan_ntiles(rt, P3_ROWS, R, q_len, sink, m); }
+static bool p3_make_plan(PaPlan& p, int sink, int m, int q_len, int G, int Hkv) { return make_plan(p, P3_ROWS, sink, m, q_len, G, Hkv); }
 
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(P3_WAVES * 64, 2) void score_rowstat3_kernel(ScoreArgs a, PaPlan plan) {
@@ -391,7 +348,7 @@ __global__ __launch_bounds__(P3_WAVES * 64, 2) void score_rowstat3_kernel(ScoreA
 }
 
 // merge of the partial statistics:  stats[0] <- (m_r, log l_r); a row tile has one partial per block that touched it
-__global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64_t rows_total) {
+__global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64_t rows_total, int unit_rows) {
     constexpr float L2E = 1.44269504088896340736f;
     float2* __restrict__ stats = a.stats;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [Hkv, stats_stride]
@@ -402,7 +359,7 @@ __global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64
         stats[i] = make_float2(INFINITY, 0.f);
         return;
     }
-    const int u = (r / P3_ROWS) * a.n_kv_heads + h;
+    const int u = (r / unit_rows) * a.n_kv_heads + h;
     // first block whose range reaches into unit u: the smallest b with (unit[b+1], tile[b+1]) > (u, 0)
     int lo = 0, hi = plan.nb - 1;
     while (lo < hi) {
