@@ -1844,9 +1844,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk)
             ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for these loads belongs here
-    }
+    }  // (no wait here: the first two row tiles are staged while these loads are in flight)
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
     const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
     const int t_begin = ysplit * per;
@@ -1892,6 +1890,8 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
     if (t_begin < t_end) {
         stage(0);
         if (t_begin + 1 < t_end) stage(1);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for the stationary keys belongs here
         stage_wait();
         block_barrier();
         u32x4 fr[2][C::KK];
@@ -1980,9 +1980,17 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
     // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        // all-reduce inside each row of 16 lanes with DPP (rotate by 8 and 4, then the two quad permutations: four VALU
+        // instructions, no LDS), one cross-row exchange through ds_bpermute
         float b = best[i];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+        auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
+        };
+        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x128>{}));  // row_ror:8
+        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x124>{}));  // row_ror:4
+        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x4E>{}));   // quad_perm:[2,3,0,1]
+        b = fmaxf(b, dpp(b, std::integral_constant<int, 0xB1>{}));   // quad_perm:[1,0,3,2]
+        b = fmaxf(b, __shfl_xor(b, 16, 64));
         best[i] = b;
     }
     if (l31 == 0) {

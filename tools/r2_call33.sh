@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python tools/ab_score.py tools/ab/lib_old.so tools/ab/lib_new.so > gpurun_out/c33_ab.log 2>&1
+bash tools/r2_call21.sh old new
