@@ -1278,14 +1278,15 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             m_ref[g] = 0.f;  // reference 0 until a block says otherwise: its sum of exponentials leaves [2^-20, 2^16] (first block
             nml2_ref[g] = 0.f;  // of the item: both bounds, later blocks: the upper one) -> cold path, reference = block maximum
             l_run[g] = 0.f;
-            int lo = rows.limit[g], hi = rows.limit[g];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo = min(lo, __shfl_xor(lo, o, 64));
-                hi = max(hi, __shfl_xor(hi, o, 64));
-            }
-            wmin[g] = __builtin_amdgcn_readfirstlane(lo);  // keys <= wmin are visible to every row of the group,
-            const int th = __builtin_amdgcn_readfirstlane(hi) / SC_TILE + 1;  // keys beyond the largest limit to none
+            // smallest / largest causal limit of the 32 rows of the group, in closed form (the rows are consecutive positions of
+            // one query head, or run over into the next one): a shuffle reduction here costs 700-1 500 cycles of LDS latency per
+            // item switch, paid at the first use of wmin (in-kernel timeline)
+            const int r0 = cur.rt * PA_ROWS + (wave * PA_RG + g) * 32;
+            const int rc0 = min(r0, R - 1), last = min(r0 + 31, R - 1);
+            const int qi0 = a.dq.mod(rc0), n = last - rc0;
+            const bool wraps = qi0 + n >= a.q_len;
+            wmin[g] = a.sink + a.m + (wraps ? 0 : qi0);                       // keys <= wmin are visible to every row of the group,
+            const int th = (a.sink + a.m + (wraps ? a.q_len - 1 : qi0 + n)) / SC_TILE + 1;  // keys beyond the largest limit to none
             t_hidden = (g == 0) ? th : max(t_hidden, th);
         }
         t_hidden = max(t_hidden, cur.t_lo + 1);
