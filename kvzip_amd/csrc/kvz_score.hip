@@ -382,6 +382,9 @@ constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
 constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
+#ifndef KVZ_PB_FUSED_SUB
+#define KVZ_PB_FUSED_SUB 1                      // pass B: x - (m_r + log l_r) through the chain's fma instead of two subtractions
+#endif
 #ifndef KVZ_PB_V2
 #define KVZ_PB_V2 1                             // same for the column-maximum kernel
 #endif
@@ -1908,7 +1911,13 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
                         auto&& hook) __attribute__((always_inline)) {
             constexpr bool ODD = decltype(odd_tag)::value;
             constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
+#if KVZ_PB_FUSED_SUB
+            // x - (m_r + log l_r): the two per-row statistics are added once per step and lane, the subtraction rides in the fma
+            // of the rounding chain (48 + 8 instead of 48 + 16 + 8 VALU instructions per 32x32 block)
+            const float neg_mr = -(st.x + st.y);
+#else
             const float neg_mr = -st.x, ll = st.y;
+#endif
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 float tv[4];
@@ -1930,11 +1939,29 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
                         accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), accn);
                     }
                 }
+#if KVZ_PB_FUSED_SUB
+                if constexpr (ODD) {
+                    // (outputs NOT tied to the inputs: the allocator answered "+v" on the loop-carried maxima with a register copy
+                    // per maximum and step; left to the compiler as plain fmaxf the maxima drift away from their block and spill)
+                    // (one instruction per statement: an output without early-clobber may share a register with an input of
+                    // its OWN instruction only)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float nb;
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(nb) : "v"(best[4 * qd + j]), "v"(hold[4 * qd + j]), "v"(tv[j]));
+                        best[4 * qd + j] = nb;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hold[4 * qd + j] = tv[j];  // (a renaming: the chain wrote the held values)
+                }
+#else
                 if constexpr (ODD)
                     quad_max(tv, ll, best[4 * qd], best[4 * qd + 1], best[4 * qd + 2], best[4 * qd + 3], hold[4 * qd], hold[4 * qd + 1],
                              hold[4 * qd + 2], hold[4 * qd + 3]);
                 else
                     quad_hold(tv, ll, hold[4 * qd], hold[4 * qd + 1], hold[4 * qd + 2], hold[4 * qd + 3]);
+#endif
                 if (qd == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     hook();
