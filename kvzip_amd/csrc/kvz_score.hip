@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL
             if (false) {
 #else
-            if (__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0) {  // wave-uniform and rare: move the reference, redo
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0, 0)) {  // wave-uniform and rare: move the reference, redo
 #endif
                 asm volatile("" ::: "memory");                                                 // (keeps it a branch)
                 const float tmax = max_packed16<T>(xp[g]);
