@@ -88,6 +88,11 @@ def _side_streams(device, n: int):
                 chosen.pop()
         except Exception:  # no spin kernel in this build: take the candidates as they come
             chosen = cands[:n]
+        import os
+        if os.environ.get("KVZ_STREAM_DEBUG"):
+            import sys
+            print("kvzip_amd: side streams = candidates", [cands.index(c) for c in chosen], "of", len(cands),
+                  "| one:", [round(_spin_time([c]), 3) for c in chosen], "all together:", round(_spin_time(chosen), 3), file=sys.stderr)
         while len(chosen) < n:  # fewer independent queues than requested: the extra streams simply do not overlap
             chosen.append(chosen[-1] if chosen else cands[0])
     _SIDE_STREAMS[key] = chosen
