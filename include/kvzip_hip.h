@@ -114,6 +114,10 @@ int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype,
  * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */
 int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int force_division, void* out_bits,
                           float* rcp_used, kvz_stream_t stream);
+/* test hook, host only: the static partition of the row-statistics pass (kvz_score.hip, PaPlan) for a geometry.
+ * unit / tile: 257 entries each; block b owns the key tiles from (unit[b], tile[b]) up to (unit[b+1], tile[b+1]). */
+int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile,
+                         int* n_blocks, int* max_seg, int* rows_per_unit);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

@@ -2401,3 +2401,19 @@ extern "C" int kvz_debug_read_trace2(unsigned long long* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace2), bytes);
 }
 #endif
+
+// test hook (host only, no GPU needed): the static partition of pass A for a geometry.  unit / tile: 257 entries each.
+extern "C" int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile, int* n_blocks,
+                                    int* max_seg, int* rows_per_unit) {
+    KVZ_REQUIRE(unit && tile && n_blocks && max_seg && rows_per_unit, KVZ_EINVAL, "kvz_debug_score_plan: null pointer");
+    KVZ_REQUIRE(sink >= 0 && m > 0 && q_len > 0 && G > 0 && Hkv > 0, KVZ_EINVAL, "kvz_debug_score_plan: bad shape");
+    PaPlan p;
+    const int rows = KVZ_PA_V3 ? P3_ROWS : PA_ROWS;
+    KVZ_REQUIRE(make_plan(p, rows, sink, m, q_len, G, Hkv), KVZ_EUNSUPPORTED, "kvz_debug_score_plan: too many units");
+    for (int b = 0; b <= PLAN_MAX_BLOCKS; ++b) { unit[b] = p.unit[b]; tile[b] = p.tile[b]; }
+    *n_blocks = p.nb;
+    *max_seg = p.max_seg;
+    *rows_per_unit = rows;
+    return KVZ_OK;
+}
+

@@ -158,3 +158,56 @@ def test_product_path_fails_loudly_without_a_device():
         ops.select_threshold(torch.rand(1, 1, 1, 16).half(), 0.3)
     with pytest.raises((KvzError, AssertionError)):
         ops.score_chunk(torch.rand(1, 2, 4, 64).half(), torch.rand(1, 1, 20, 64).half(), 0, 0, 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# static partition of the row-statistics pass (kvz_score.hip: PaPlan) - host code, no GPU needed
+# ------------------------------------------------------------------------------------------------
+def _score_plan(sink, m, q_len, G, Hkv):
+    import ctypes as C
+    from kvzip_amd import _lib
+    lib = _lib.load()
+    unit, tile = (C.c_uint16 * 257)(), (C.c_uint16 * 257)()
+    nb, max_seg, rows = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib.kvz_debug_score_plan(sink, m, q_len, G, Hkv, unit, tile, C.byref(nb), C.byref(max_seg), C.byref(rows))
+    assert rc == 0
+    return list(unit), list(tile), nb.value, max_seg.value, rows.value
+
+
+def _ntiles(rt, rows, R, q_len, sink, m):
+    r0, r1 = rt * rows, min(R - 1, rt * rows + rows - 1)
+    qmax = (r1 % q_len) if r0 // q_len == r1 // q_len else q_len - 1
+    return (sink + m + qmax + 1 + 127) // 128
+
+
+@pytest.mark.parametrize("geom", [(32, 2000, 2026, 7, 4), (32, 2000, 2013, 7, 4), (32, 2000, 2026, 4, 8), (16, 600, 626, 4, 2),
+                                  (4, 32, 40, 7, 4), (0, 1, 1, 1, 1), (30, 700, 713, 7, 2), (32, 2000, 2026, 8, 1),
+                                  (8, 100, 3000, 2, 1), (32, 1072, 1098, 7, 4), (0, 5000, 5026, 16, 16), (40, 129, 17, 5, 3)])
+def test_score_plan_is_a_partition(geom):
+    """Every key tile of every (row tile, head) unit belongs to exactly one block, blocks are ordered and non-empty, the last cut
+    is the end of the sequence, ranges differ by a bounded amount, and `max_seg` bounds the partial statistics per unit."""
+    sink, m, q_len, G, Hkv = geom
+    unit, tile, nb, max_seg, rows = _score_plan(sink, m, q_len, G, Hkv)
+    R = G * q_len
+    RT = (R + rows - 1) // rows
+    U = RT * Hkv
+    nt = [_ntiles(u // Hkv, rows, R, q_len, sink, m) for u in range(U)]
+    total = sum(nt)
+    assert 1 <= nb <= 256 and nb == min(256, total)
+    assert (unit[0], tile[0]) == (0, 0) and (unit[nb], tile[nb]) == (U, 0)
+    pref = [0]
+    for x in nt:
+        pref.append(pref[-1] + x)
+    cuts = []
+    for b in range(nb + 1):
+        assert unit[b] <= U and (unit[b] == U or tile[b] < nt[unit[b]])
+        cuts.append(pref[unit[b]] + tile[b])
+    sizes = [cuts[b + 1] - cuts[b] for b in range(nb)]
+    assert all(s >= 1 for s in sizes) and sum(sizes) == total
+    assert max(sizes) <= 2 * (total / nb) + 2            # (tiles that hold a causal limit weigh 1.5: ranges are equal up to that)
+    touched = [0] * U                                      # blocks per unit
+    for b in range(nb):
+        u0, u1 = unit[b], unit[b + 1] if tile[b + 1] > 0 else unit[b + 1] - 1
+        for u in range(u0, min(u1, U - 1) + 1):
+            touched[u] += 1
+    assert max(touched) <= max_seg
