@@ -268,7 +268,8 @@ size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max
 /* k_meta_host (optional, HOST pointer, may be NULL): [k_start[0..Hkv), k_len[0..Hkv)] as the caller knows them on the host (the
  * cache object does: one D2H copy per prune).  With it the kernel gets the head segments as launch arguments and does not start
  * with a dependent load of the device arrays.  Up to 64 heads; ignored beyond.
- * ws: kvz_varlen_attn_workspace_bytes(...) bytes, ZERO-FILLED when first used (arrival counters; every call leaves them zero). */
+ * ws: kvz_varlen_attn_workspace_bytes(...) bytes of scratch (partial results of the key ranges, or of the key splits of the
+ * multi-row kernel); no initialisation needed, the size does not depend on max_len_k. */
 int kvz_varlen_attn(const void* q, const void* k, const void* v,
                     const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
                     int Hkv, int G, int q_len, int D, int max_len_k,

@@ -317,8 +317,8 @@ def append_inplace(k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.
 # a13  variable-length attention
 # --------------------------------------------------------------------------------------------------
 def attn_workspace(Hkv: int, G: int, q_len: int, D: int, device) -> torch.Tensor:
-    """Scratch of the attention kernel: partial results of the key ranges + one arrival counter per (head, row tile).  It must be
-    ZERO-FILLED when first used (every call leaves the counters at zero), so it is allocated with torch.zeros."""
+    """Scratch of the attention kernels: partial results of the key ranges (decode kernel) or of the key splits (multi-row kernel).
+    No initialisation is required; it is zero-filled once anyway (a reserved counter region of the layout)."""
     need = _lib.load().kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, 0)
     return torch.zeros(max(int(need), 16), dtype=torch.uint8, device=device)
 
