@@ -118,6 +118,8 @@ int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int forc
  * unit / tile: 257 entries each; block b owns the key tiles from (unit[b], tile[b]) up to (unit[b+1], tile[b+1]). */
 int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile,
                          int* n_blocks, int* max_seg, int* rows_per_unit);
+/* test hook, host only: n / d and n % d as the kernels compute them (multiply-shift by a launch-invariant divisor). */
+int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

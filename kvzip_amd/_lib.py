@@ -37,6 +37,7 @@ SIGNATURES = {
     "kvz_score_finalize_log": (_i, [_vp, _i64, _vp, _i, _vp]),
     "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
+    "kvz_debug_fastdiv": (_i, [_i, _i, _vp, _vp]),
     "kvz_debug_score_plan": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -2417,3 +2417,12 @@ extern "C" int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, 
     return KVZ_OK;
 }
 
+// test hook (host only): quotient of the invariant-divisor arithmetic used inside the kernels (FastDiv), n in [0, 2^31)
+extern "C" int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder) {
+    KVZ_REQUIRE(d > 0 && n >= 0 && quotient && remainder, KVZ_EINVAL, "kvz_debug_fastdiv: bad arguments");
+    const FastDiv f = make_fastdiv(d);
+    *quotient = f.div(n);
+    *remainder = f.mod(n);
+    return KVZ_OK;
+}
+

@@ -211,3 +211,24 @@ def test_score_plan_is_a_partition(geom):
         for u in range(u0, min(u1, U - 1) + 1):
             touched[u] += 1
     assert max(touched) <= max_seg
+
+
+def test_fastdiv_matches_integer_division():
+    """The kernels divide by launch-invariant integers (q_len, Hkv, items per slice) with a multiply-shift (Granlund-Montgomery
+    round-up, exact for 31-bit numerators): compare with Python's // and % on edge and random values."""
+    import ctypes as C
+    import random
+    from kvzip_amd import _lib
+    lib = _lib.load()
+    rng = random.Random(5)
+    q, r = C.c_int(0), C.c_int(0)
+    divisors = [1, 2, 3, 4, 5, 7, 8, 13, 26, 28, 31, 32, 33, 127, 128, 129, 224, 626, 713, 1000, 2013, 2026, 4096, 65535, 65536,
+                65537, 1 << 20, (1 << 30) - 1, 1 << 30, (1 << 31) - 1] + [rng.randint(1, (1 << 31) - 1) for _ in range(40)]
+    for d in divisors:
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - 2, 1 << 30] + [rng.randint(0, (1 << 31) - 1) for _ in range(200)]
+        ns += [k * d + off for k in (1, 7, 1000, ((1 << 31) - 1) // d) for off in (-1, 0, 1)]
+        for n in ns:
+            if not 0 <= n < (1 << 31):
+                continue
+            assert lib.kvz_debug_fastdiv(d, n, C.byref(q), C.byref(r)) == 0
+            assert (q.value, r.value) == (n // d, n % d), (d, n, q.value, r.value)
