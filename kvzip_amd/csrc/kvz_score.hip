@@ -1256,7 +1256,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         sq_stage(1);
         staged = 2;
     }
-    stage_wait();
+    // the query rows and the first tile are needed now, the second tile at the first hand-over (which waits for it)
+    if (staged == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else stage_wait();
     block_barrier();
     v8 bq[PA_RG][C::KK];
     read_q(bq);
