@@ -62,16 +62,6 @@ constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 12
 #endif
 constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
 constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
-#ifndef KVZ_KSPLIT_TILES
-#define KVZ_KSPLIT_TILES 8
-#endif
-// pass A with the snake schedule (KVZ_PA_PLAN=0): key tiles per work item.  Alone on the GPU 4 is fastest (8: +5 %, the tail of
-// unevenly loaded blocks), but in the scoring loop the calls of consecutive layers overlap and the tail is filled by the next
-// kernel: there the WORK counts, and 8 halves the item switches (~3 000 cycles each, all eight waves): +6.5 % tokens/s in
-// bench.py (16 and 32: +5 %).  The balanced partition (KVZ_PA_PLAN=1, default) has neither the tail nor the extra switches.
-constexpr int SC_KSPLIT_TILES = KVZ_KSPLIT_TILES;
-constexpr int SC_PERSISTENT_BLOCKS = 256;          // pass A: one persistent block per CU
-
 // division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
 // l = ceil(log2 d) (Granlund-Montgomery round-up method, exact for 31-bit numerators).  A 32-bit division costs ~20 instructions;
 // the item switch of pass A had nine of them, executed by all eight waves.
@@ -97,9 +87,8 @@ struct ScoreArgs {
     const void* k;       // [Hkv, klen, D]
     int64_t q_head_stride, k_head_stride;  // elements
     int klen, sink, start, m, q_len, G;
-    float2* stats;       // [key_splits, Hkv, stats_stride]  partial (m_r, l'_r) of each key slice (l' relative to fl(m*log2e))
+    float2* stats;       // [max_seg, Hkv, stats_stride]  partial (m_r, l'_r) of each segment (l' relative to fl(m*log2e))
     int stats_stride;    // G*q_len rounded up to a multiple of SC_TILE; the padding rows hold (+inf, 0) after the merge
-    int key_splits;      // pass A: slices of SC_KSPLIT_TILES key tiles
     float* colpart;      // [row_splits, Hkv, m]  per-slice column maxima of the log-softmax
     void* out;           // [Hkv, m] half
     int64_t out_head_stride;
@@ -107,7 +96,7 @@ struct ScoreArgs {
     int n_kv_heads;
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
-    FastDiv dq, dh, dz;  // q_len, Hkv, work items per key slice of pass A
+    FastDiv dq, dh;      // q_len, Hkv
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
 };
@@ -133,32 +122,6 @@ __device__ static inline T round_chain_h(float acc, float c, float rcp) {
     const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
     return (T)d;
 }
-// maximum of 16 values of T as fp32 (fp16: packed v_pk_max_f16 on pairs)
-template <typename T>
-__device__ static inline float max16(const T (&hx)[16]) {
-    if constexpr (std::is_same<T, _Float16>::value) {
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        h2v m = {hx[0], hx[1]};
-#pragma unroll
-        for (int i = 2; i < 16; i += 2) m = __builtin_elementwise_max(m, h2v{hx[i], hx[i + 1]});
-        return fmaxf((float)m[0], (float)m[1]);
-    } else {
-        float m = (float)hx[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) m = fmaxf(m, (float)hx[i]);
-        return m;
-    }
-}
-
-// ---- packed form of the chain: 16 accumulators -> 8 registers holding two 16-bit results each (lo = even, hi = odd) ----
-// fp16 with the exact reciprocal: v_cvt_pk_f16_f32 (first rounding, two values per instruction) followed by
-// v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp32 product of the 16-bit value and rcp, rounded once to fp16, in place).
-// The mix instructions (and the packed maximum tree of pass A) are written as ONE inline-assembly block per 32x32
-// result: left to instruction selection, the second rounding is emitted twice (packed for the maximum, scalar for
-// the exponent) and every packed maximum gets a canonicalising copy - 8.2 instead of 4.6 VALU instructions per logit.
-// Hazards: the MFMA -> VALU wait states are on the compiler-visible conversions; inside the block every consumer is
-// at least one instruction behind its producer (gfx950 needs one wait state after a 16-bit-destination / packed
-// producer), and the block starts and ends with s_nop 0 for the instructions the compiler places around it.
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <typename T> __device__ static inline uint32_t bits16(T v) {
@@ -173,67 +136,6 @@ template <typename T> __device__ static inline float pair_lo(uint32_t p) {
 template <typename T> __device__ static inline float pair_hi(uint32_t p) {
     if constexpr (std::is_same<T, _Float16>::value) return (float)__builtin_bit_cast(h2v, p)[1];
     else return __builtin_bit_cast(float, p & 0xffff0000u);
-}
-// float(16-bit half HI of p) + addend, one rounding (fp16: v_fma_mix_f32 reads the half directly; written as assembly
-// because fma(x, 1, y) is canonicalised to an add with a separate conversion)
-template <typename T, int HI> __device__ static inline float pair_sub(uint32_t p, float neg_m) {
-    if constexpr (std::is_same<T, _Float16>::value) {
-        float r;
-        if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(neg_m));
-        else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(neg_m));
-        return r;
-    } else {
-        return (HI ? pair_hi<T>(p) : pair_lo<T>(p)) + neg_m;
-    }
-}
-#define KVZ_MIXLO(i) "v_fma_mixlo_f16 %" #i ", %" #i ", %[r], 0 op_sel_hi:[1,0,0]\n\t"
-#define KVZ_MIXHI(i) "v_fma_mixhi_f16 %" #i ", %" #i ", %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-#define KVZ_MIX_ALL                                                                                                   \
-    "s_nop 0\n\t" KVZ_MIXLO(0) KVZ_MIXLO(1) KVZ_MIXLO(2) KVZ_MIXLO(3) KVZ_MIXLO(4) KVZ_MIXLO(5) KVZ_MIXLO(6) KVZ_MIXLO(7) \
-        KVZ_MIXHI(0) KVZ_MIXHI(1) KVZ_MIXHI(2) KVZ_MIXHI(3) KVZ_MIXHI(4) KVZ_MIXHI(5) KVZ_MIXHI(6) KVZ_MIXHI(7)
-// xp <- chain of the 16 accumulators; returns the maximum of the 16 results when WITH_MAX (else 0)
-template <typename T, bool FAST, bool WITH_MAX>
-__device__ static inline float chain_block(const float (&acc)[16], uint32_t (&xp)[8], float c, float rcp) {
-    if constexpr (std::is_same<T, _Float16>::value && FAST) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-            xp[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{acc[2 * p], acc[2 * p + 1]}, h2v));
-        if constexpr (WITH_MAX) {
-            uint32_t m0, m1, m2, m3;
-            asm(KVZ_MIX_ALL
-                "v_pk_max_f16 %[m0], %0, %1\n\t"
-                "v_pk_max_f16 %[m1], %2, %3\n\t"
-                "v_pk_max_f16 %[m2], %4, %5\n\t"
-                "v_pk_max_f16 %[m3], %6, %7\n\t"
-                "v_pk_max_f16 %[m0], %[m0], %[m1]\n\t"
-                "v_pk_max_f16 %[m2], %[m2], %[m3]\n\t"
-                "s_nop 0\n\t"
-                "v_pk_max_f16 %[m0], %[m0], %[m2]\n\t"
-                "s_nop 0"
-                : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]), "+v"(xp[4]), "+v"(xp[5]), "+v"(xp[6]), "+v"(xp[7]),
-                  [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3)
-                : [r] "s"(rcp));
-            const h2v m = __builtin_bit_cast(h2v, m0);
-            return fmaxf((float)m[0], (float)m[1]);
-        } else {
-            asm(KVZ_MIX_ALL "s_nop 0"
-                : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]), "+v"(xp[4]), "+v"(xp[5]), "+v"(xp[6]), "+v"(xp[7])
-                : [r] "s"(rcp));
-            return 0.f;
-        }
-    } else {
-        float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const T x0 = round_chain_h<T, FAST>(acc[2 * p], c, rcp), x1 = round_chain_h<T, FAST>(acc[2 * p + 1], c, rcp);
-            xp[p] = bits16(x0) | (bits16(x1) << 16);
-            if (WITH_MAX) {
-                m0 = fmaxf(m0, (float)x0);
-                m1 = fmaxf(m1, (float)x1);
-            }
-        }
-        return fmaxf(m0, m1);
-    }
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -381,371 +283,6 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
-constexpr int PA_NBUF = 2;                      // LDS key-tile buffers
-#ifndef KVZ_PB_FUSED_SUB
-#define KVZ_PB_FUSED_SUB 1                      // pass B: x - (m_r + log l_r) through the chain's fma instead of two subtractions
-#endif
-#ifndef KVZ_PB_V2
-#define KVZ_PB_V2 1                             // same for the column-maximum kernel
-#endif
-#ifndef KVZ_PA_V3
-#define KVZ_PA_V3 0                             // 1: 64 rows per wave + exactly balanced static partition (kvz_score_pa3.h): measured
-#endif                                          // -2 % at D = 64, does not fit the register file at D = 128 - off
-#ifndef KVZ_PA_PLAN
-#define KVZ_PA_PLAN 1                           // 1: exactly balanced static partition (PaPlan) instead of the snake schedule of key slices
-#endif
-#ifndef KVZ_PA_V2
-#define KVZ_PA_V2 1                             // 1: software-pipelined row-statistics kernel (round 2); 0: round-1 kernel
-#endif
-
-// keys of the virtual sequence  sink ++ ctx chunk ++ repeat chunk  ->  rows of the cache (slow, per-lane path)
-struct KeyMap {
-    const char* kh;
-    int KT, sink, m, off_ctx, off_rep;
-};
-template <int D, int NW>
-__device__ __attribute__((noinline)) static void stage_keys_gather(char* buf, KeyMap km, int kv0, int wave, int lane) {
-    typedef ScoreCfg<D> C;
-    auto keyptr = [&](int kv) -> const char* {
-        kv = min(kv, km.KT - 1);
-        const int row = kv + (kv < km.sink ? 0 : (kv < km.sink + km.m ? km.off_ctx : km.off_rep));
-        return km.kh + (int64_t)row * C::ROW_BYTES;
-    };
-    stage_tile<D, NW>(buf, kv0, keyptr, wave, lane);
-}
-// 32 query rows (one row group of one wave) -> LDS, same swizzle as a key tile; rows beyond R shadow row R-1
-struct RowMap {
-    const char* qh;  // first query head of the KV head
-    int64_t head_stride_bytes;
-    int q_len, R;
-};
-template <int D>
-__device__ __attribute__((noinline)) static void stage_rows32(char* buf, RowMap rm, int r0, int lane) {
-    typedef ScoreCfg<D> C;
-    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
-#pragma unroll
-    for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
-        const int row = i * ROWS_PER_INSTR + lane / C::CPR;
-        const int p = lane % C::CPR;
-        const int chunk = (D == 128) ? (p ^ (row & 15)) : (p ^ ((row >> 1) & 7));
-        const int r = min(r0 + row, rm.R - 1);
-        const int g = r / rm.q_len;
-        const int qi = r - g * rm.q_len;
-        lds_dma16(rm.qh + g * rm.head_stride_bytes + (int64_t)qi * C::ROW_BYTES + chunk * 16, buf + i * 1024);
-    }
-}
-
-template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat_kernel(ScoreArgs a) {
-    constexpr int NWAVES = PA_WAVES;
-    typedef ScoreCfg<D> C;
-    typedef typename Mfma32<T>::v8 v8;
-    constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
-    __shared__ __attribute__((aligned(16))) char lds[PA_NBUF * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
-    char* const qarea = lds + PA_NBUF * C::TILE_BYTES;
-    constexpr float L2E = 1.44269504088896340736f;
-
-    const int R = a.G * a.q_len;
-    const int KT = a.sink + a.m + a.q_len;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int diag0 = a.sink + a.m;  // first key that can be masked for some row
-    const int off_ctx = a.start - a.sink;                       // virtual -> cache row, ctx segment
-    const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
-    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
-
-    // ---- work items: index -> (key slice z, row tile rt, head h); z ascending = heaviest (unmasked) slices first ----
-    const int RT = (R + PA_ROWS - 1) / PA_ROWS;
-    const int per_z = RT * a.n_kv_heads;
-    const int nitems = per_z * a.key_splits;
-    struct Item { int k, h, rt, z, t_lo, t_hi; };  // k = position in this block's list; t_lo >= t_hi: none
-    auto decode = [&](int i) __attribute__((always_inline)) -> Item {
-        Item it;
-        it.k = 0;
-        it.z = i / per_z;
-        const int rem = i - it.z * per_z;
-        it.rt = rem / a.n_kv_heads;
-        it.h = rem - it.rt * a.n_kv_heads;
-        // loop bound of the row tile: the largest causal limit of any of its rows
-        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
-        const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
-        const int ntiles = (min(KT, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
-        it.t_lo = it.z * SC_KSPLIT_TILES;
-        it.t_hi = min(ntiles, it.t_lo + SC_KSPLIT_TILES);
-        return it;
-    };
-    // static snake schedule: the k-th item of block b is k*G + b (k even) or (k+1)*G - 1 - b (k odd); empty items (key
-    // slices beyond the causal limit of their row tile) are skipped
-    const int G_ = gridDim.x;
-    auto item_from = [&](int k) -> Item {  // first non-empty item at list position >= k
-        Item it;
-        it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
-        for (;; ++k) {
-            const int i = (k & 1) ? (k + 1) * G_ - 1 - (int)blockIdx.x : k * G_ + (int)blockIdx.x;
-            if (k * G_ >= nitems) return it;  // whole round beyond the list
-            if (i >= nitems) continue;
-            Item c = decode(i);
-            if (c.t_lo < c.t_hi) {
-                c.k = k;
-                return c;
-            }
-        }
-    };
-    auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
-    auto head_keys = [&](int h) -> const char* { return reinterpret_cast<const char*>(a.k) + (int64_t)h * a.k_head_stride * 2; };
-    // stage key tile t of head h into LDS buffer b: linear when its 128 keys lie in one segment (sink / ctx / repeat)
-    auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
-        char* dst = lds + b * C::TILE_BYTES;
-        const char* kh = head_keys(h);
-        const int kv0 = t * SC_TILE, kv1 = kv0 + SC_TILE - 1;
-        int off = 0;
-        bool linear = kv1 < KT;
-        if (kv1 < a.sink) off = 0;
-        else if (kv0 >= a.sink + a.m) off = off_rep;
-        else if (kv0 >= a.sink && kv1 < a.sink + a.m) off = off_ctx;
-        else linear = false;
-        if (linear) stage_tile_linear<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
-        else stage_keys_gather<D, NWAVES>(dst, KeyMap{kh, KT, a.sink, a.m, off_ctx, off_rep}, kv0, wave, lane);
-    };
-    // this wave's 64 query rows of an item -> its private LDS area (two row groups)
-    auto stage_q = [&](const Item& it) __attribute__((always_inline)) {
-        const RowMap rm{reinterpret_cast<const char*>(a.q) + (int64_t)it.h * a.G * a.q_head_stride * 2, a.q_head_stride * 2, a.q_len, R};
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g)
-            stage_rows32<D>(qarea + (wave * PA_RG + g) * QG_BYTES, rm, it.rt * PA_ROWS + (wave * PA_RG + g) * 32, lane);
-    };
-    FragAddr<D> fa0;
-    fa0.init(lds, l31, half);
-    // B operand (one query row per lane) of the two row groups, from the wave's LDS area
-    auto read_q = [&](v8 (&dst)[PA_RG][C::KK]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g) {
-            FragAddr<D> fq;
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) fq.a[kk] = fa0.a[kk] + (uint32_t)(PA_NBUF * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
-            u32x4 tmp[C::KK];
-            frag_load<D>(tmp, fq, 0);
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) dst[g][kk] = __builtin_bit_cast(v8, tmp[kk]);
-        }
-    };
-    // per-lane row bookkeeping of an item
-    struct Rows { int r[PA_RG], limit[PA_RG]; };
-    auto rows_of = [&](const Item& it) __attribute__((always_inline)) -> Rows {
-        Rows w;
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g) {
-            w.r[g] = it.rt * PA_ROWS + (wave * PA_RG + g) * 32 + l31;
-            const int rc = min(w.r[g], R - 1);
-            w.limit[g] = a.sink + a.m + rc % a.q_len;  // key j (virtual index) is visible to query i iff j <= sink + m + i  (score.py:67-85)
-        }
-        return w;
-    };
-    // A fragments (key rows) of one 32-key block: all LDS reads are issued together, one block AHEAD of their use
-    // (the addresses of the buffer in use are computed once per tile: fcur)
-    FragAddr<D> fcur = fa0;
-    auto set_frag_buffer = [&](int b) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) fcur.a[kk] = fa0.a[kk] + (uint32_t)(b * C::TILE_BYTES);
-    };
-    auto load_frags = [&](u32x4 (&fr)[C::KK], int kb /* compile-time */) __attribute__((always_inline)) {
-        frag_load<D>(fr, fcur, kb * 32 * C::ROW_BYTES);
-    };
-
-    Item cur = item_from(0);
-    if (!valid(cur)) return;
-    Item nxt = item_from(cur.k + 1);
-    // stage cursor: the next tile of the stream that has not been staged yet
-    bool sq_in_next = false, sq_done = false;
-    int sq_t = cur.t_lo;
-    auto sq_stage = [&](int b) __attribute__((always_inline)) {  // stage the cursor's tile into buffer b and advance
-        stage(b, sq_in_next ? nxt.h : cur.h, sq_t);
-        ++sq_t;
-        if (sq_t >= (sq_in_next ? nxt.t_hi : cur.t_hi)) {
-            if (!sq_in_next && valid(nxt)) {
-                sq_in_next = true;
-                sq_t = nxt.t_lo;
-            } else {
-                sq_done = true;
-            }
-        }
-    };
-    stage_q(cur);
-    sq_stage(0);
-    bool ahead = false;  // the tile after the current one is staged
-    if (!sq_done) {
-        sq_stage(1);
-        ahead = true;
-    }
-    stage_wait();
-    block_barrier();
-    v8 bq[PA_RG][C::KK];
-    read_q(bq);
-    u32x4 fr[2][C::KK];
-    load_frags(fr[0], 0);
-#pragma unroll
-    for (int g = 0; g < PA_RG; ++g)
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
-    if (valid(nxt)) stage_q(nxt);
-    Rows rows = rows_of(cur);
-
-    int pbuf = 0;  // buffer of the tile being computed
-    int t = cur.t_lo;
-    float m_run[PA_RG], ml2_run[PA_RG], l_run[PA_RG];
-    int wmin[PA_RG], wmax[PA_RG];
-    auto start_item = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g) {
-            m_run[g] = -INFINITY;
-            ml2_run[g] = 0.f;
-            l_run[g] = 0.f;
-            // causal limits of the group's 32 rows (wave-uniform): a 32-key block is fully visible to the group if its
-            // last key <= wmin, fully masked if its first key > wmax; only the blocks in between need the per-logit test
-            int lo = rows.limit[g], hi = rows.limit[g];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo = min(lo, __shfl_xor(lo, o, 64));
-                hi = max(hi, __shfl_xor(hi, o, 64));
-            }
-            wmin[g] = __builtin_amdgcn_readfirstlane(lo);
-            wmax[g] = __builtin_amdgcn_readfirstlane(hi);
-        }
-    };
-    start_item();
-
-    // rounding chain + online softmax of one 32-key block of row group g whose first key is k0; MASK = per-logit causal test
-    auto epilogue = [&](const f16v& acc, int k0, auto g_tag, auto mask_tag) __attribute__((always_inline)) {
-        constexpr int g = decltype(g_tag)::value;
-        constexpr bool MASK = decltype(mask_tag)::value;
-        uint32_t xp[8];
-        float av[16];
-        const int rel = rows.limit[g] - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) visible iff <= rel
-#pragma unroll
-        for (int i = 0; i < 16; ++i)  // -inf survives the chain: half(-inf) = -inf, -inf * rcp = -inf / c = -inf
-            av[i] = (!MASK || (i & 3) + 8 * (i >> 2) <= rel) ? acc[i] : -INFINITY;
-        const float tmax = chain_block<T, FAST, true>(av, xp, a.c, a.rcp);
-        if (__builtin_amdgcn_ballot_w64(tmax > m_run[g]) != 0) {  // wave-uniform branch: rare after the first blocks
-            asm volatile("" ::: "memory");                        // (keeps it a branch: if-conversion costs 16 VALU / block)
-            if (tmax > m_run[g]) {  // new running maximum: rescale the partial sum
-                const float ml2_new = tmax * L2E;
-                l_run[g] *= __builtin_amdgcn_exp2f(ml2_run[g] - ml2_new);  // m_run = -inf: l_run is 0 and ml2_run finite
-                m_run[g] = tmax;
-                ml2_run[g] = ml2_new;
-            }
-        }
-        float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            ps0 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xp[p]), L2E, -ml2_run[g]));
-            ps1 += __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xp[p]), L2E, -ml2_run[g]));
-        }
-        l_run[g] += ps0 + ps1;  // (masked keys: x = -inf -> exp2(-inf) = 0)
-    };
-    // hand-over of the current tile's buffer (between its last matrix chains and its last epilogues)
-    bool ahead_next = false, late = false;
-    auto turnover = [&]() __attribute__((always_inline)) {
-        stage_wait();     // my part of everything in flight (the next tile, the next item's query rows) has landed
-        block_barrier();  // ... everybody's has, and nobody reads the current buffer any more
-        if (ahead) {  // normal case: tile p+1 is in the other buffer; refill this one with tile p+2
-            ahead_next = !sq_done;
-            if (!sq_done) sq_stage(pbuf);
-            set_frag_buffer(pbuf ^ 1);
-            load_frags(fr[0], 0);
-        } else {      // the stream was starved (items of a single tile) or ends here: both buffers are free
-            late = !sq_done;
-            if (!sq_done) sq_stage(pbuf ^ 1);
-            ahead_next = !sq_done;
-            if (!sq_done) sq_stage(pbuf);
-        }
-    };
-    // one 128-key tile = 4 blocks of 32 keys x PA_RG row groups; DIAG = tile straddles / lies beyond the causal diagonal
-    auto tile_body = [&](auto diag_tag) __attribute__((always_inline)) {
-        constexpr bool DIAG = decltype(diag_tag)::value;
-#pragma unroll
-        for (int kb = 0; kb < SC_TILE / 32; ++kb) {
-            const int k0 = t * SC_TILE + kb * 32;
-            bool skip[PA_RG];
-            f16v acc[PA_RG];
-#pragma unroll
-            for (int g = 0; g < PA_RG; ++g) {
-                skip[g] = DIAG && k0 > wmax[g];  // nothing of this block is visible to any row of the group
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the chains of different row groups are independent and are issued ALTERNATELY
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk)
-#pragma unroll
-                for (int g = 0; g < PA_RG; ++g)
-                    if (!skip[g]) acc[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, fr[kb & 1][kk]), bq[g][kk], acc[g]);
-            if (kb + 1 < SC_TILE / 32) load_frags(fr[(kb + 1) & 1], kb + 1);
-            else turnover();
-            __builtin_amdgcn_sched_barrier(0);
-            auto epi = [&](auto g_tag) __attribute__((always_inline)) {
-                constexpr int g = decltype(g_tag)::value;
-                if (skip[g]) return;
-                if (DIAG && k0 + 31 > wmin[g]) epilogue(acc[g], k0, g_tag, std::true_type{});
-                else epilogue(acc[g], k0, g_tag, std::false_type{});
-            };
-            epi(std::integral_constant<int, 0>{});
-            if constexpr (PA_RG > 1) epi(std::integral_constant<int, PA_RG - 1>{});
-        }
-    };
-
-    while (true) {
-        if ((t * SC_TILE + SC_TILE - 1) > diag0) tile_body(std::true_type{});   // also covers kv >= KT
-        else tile_body(std::false_type{});
-        pbuf ^= 1;
-        ahead = ahead_next;
-        if (late) {  // (rare) the next tile could only be staged at the hand-over: wait for it here
-            stage_wait();
-            block_barrier();
-            set_frag_buffer(pbuf);
-            load_frags(fr[0], 0);
-            late = false;
-        }
-        if (++t < cur.t_hi) continue;
-
-        // ---- item finished: partial statistics of this key slice ----
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g) {
-            // merge the two half-waves (they saw disjoint keys of the same query row)
-            const float m_o = __shfl_xor(m_run[g], 32, 64);
-            const float ml2_o = __shfl_xor(ml2_run[g], 32, 64);
-            const float l_o = __shfl_xor(l_run[g], 32, 64);
-            const float M = fmaxf(m_run[g], m_o);
-            const float ML2 = (m_run[g] >= m_o) ? ml2_run[g] : ml2_o;
-            const float Lp = l_run[g] * __builtin_amdgcn_exp2f(ml2_run[g] - ML2) + l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
-            if (half == 0 && rows.r[g] < R)
-                a.stats[((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + rows.r[g]] = make_float2(M, Lp);
-        }
-        if (!valid(nxt)) break;
-        // ---- switch to the next item: its first tile is in LDS (fragments already prefetched), its query rows landed
-        // before the last hand-over ----
-        cur = nxt;
-        nxt = item_from(cur.k + 1);
-        t = cur.t_lo;
-        rows = rows_of(cur);
-        read_q(bq);
-#pragma unroll
-        for (int g = 0; g < PA_RG; ++g)
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // rows in registers: the area is free again
-        if (valid(nxt)) stage_q(nxt);
-        if (sq_in_next) {  // the cursor was already inside the item that is now current
-            sq_in_next = false;
-            if (sq_done && valid(nxt)) {
-                sq_done = false;
-                sq_in_next = true;
-                sq_t = nxt.t_lo;
-            }
-        }
-        start_item();
-    }
-}
 
 // ---- pass A, software-pipelined form (round 2) ------------------------------------------------------------------------
 // Same tiling, staging, static schedule and hand-over protocol as score_rowstat_kernel; what changes is the instruction
@@ -1049,31 +586,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
     const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
 
-    // ---- work items and static snake schedule: identical to score_rowstat_kernel ----
-    const int RT = (R + PA_ROWS - 1) / PA_ROWS;
-    const int per_z = RT * a.n_kv_heads;
-    const int nitems = per_z * a.key_splits;
-    struct Item { int k, h, rt, z, t_lo, t_hi; };
-    auto decode = [&](int i) __attribute__((always_inline)) -> Item {
-        Item it;
-        it.k = 0;
-        it.z = a.dz.div(i);
-        const int rem = i - it.z * per_z;
-        it.rt = a.dh.div(rem);
-        it.h = rem - it.rt * a.n_kv_heads;
-        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
-        const int h0 = a.dq.div(r0), h1 = a.dq.div(r1);
-        const int qmax = (h0 == h1) ? (r1 - h1 * a.q_len) : (a.q_len - 1);
-        const int ntiles = (min(KT, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
-        it.t_lo = it.z * SC_KSPLIT_TILES;
-        it.t_hi = min(ntiles, it.t_lo + SC_KSPLIT_TILES);
-        return it;
-    };
-    const int G_ = gridDim.x;
-#if KVZ_ABL & 1
-    bool abl_first = true;
-#endif
-#if KVZ_PA_PLAN
+    struct Item { int k, h, rt, z, t_lo, t_hi; };  // unit, KV head, row tile, ordinal of the partial, key tiles [t_lo, t_hi)
     // exactly balanced static partition (PaPlan): this block's range of the tile sequence, walked as segments; Item.k = unit
     const int u_first = plan.unit[blockIdx.x], t_first = plan.tile[blockIdx.x];
     const int u_end = plan.unit[blockIdx.x + 1], t_end = plan.tile[blockIdx.x + 1];  // exclusive: (u_end, t_end)
@@ -1098,24 +611,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         return it;
     };
     const int first_item = u_first;
-    (void)decode; (void)nitems; (void)G_;
-#else
-    const int first_item = 0;
-    auto item_from = [&](int k) -> Item {
-        Item it;
-        it.k = k; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
-        for (;; ++k) {
-            const int i = (k & 1) ? (k + 1) * G_ - 1 - (int)blockIdx.x : k * G_ + (int)blockIdx.x;
-            if (k * G_ >= nitems) return it;
-            if (i >= nitems) continue;
-            Item c = decode(i);
-            if (c.t_lo < c.t_hi) {
-                c.k = k;
-                return c;
-            }
-        }
-    };
-#endif
     auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
     // tiles (128 consecutive virtual keys) that lie inside ONE segment are consecutive rows of the cache: [tc_lo, tc_hi) inside
     // the ctx chunk, [tr_lo, tr_hi) inside the repeat chunk, [0, ts_hi) inside the sink; every other tile straddles a boundary
@@ -1607,25 +1102,29 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     }
 }
 
-#include "kvz_score_pa3.h"
-
-// merge the key slices of pass A:  stats[0] <- (m_r, log l_r).  l'_s is relative to fl(m_s*log2e); the common factor
-// 2^(M*log2e - fl(M*log2e)) is removed exactly (delta).  Only the slices below the causal limit of the row's tile exist.
-__global__ void score_merge_stats_kernel(ScoreArgs a, int R, int64_t rows_total) {
+// merge of the partial statistics:  stats[0] <- (m_r, log l_r); a row tile has one partial per block that touched it
+__global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64_t rows_total, int unit_rows) {
     constexpr float L2E = 1.44269504088896340736f;
-    constexpr int SC_COLS = PA_ROWS;
     float2* __restrict__ stats = a.stats;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [Hkv, stats_stride]
     if (i >= rows_total) return;
     const int r = (int)(i % a.stats_stride);
-    if (r >= R) {  // padding row: (m = +inf) makes x - m = -inf in pass B, it never wins a maximum
+    const int h = (int)(i / a.stats_stride);
+    if (r >= R) {
         stats[i] = make_float2(INFINITY, 0.f);
         return;
     }
-    const int r0 = r / SC_COLS * SC_COLS, r1 = min(R - 1, r0 + SC_COLS - 1);
-    const int qmax = (r0 / a.q_len == r1 / a.q_len) ? (r1 % a.q_len) : (a.q_len - 1);
-    const int ntiles = (min(a.sink + a.m + a.q_len, a.sink + a.m + qmax + 1) + SC_TILE - 1) / SC_TILE;
-    const int slices = min(a.key_splits, (ntiles + SC_KSPLIT_TILES - 1) / SC_KSPLIT_TILES);
+    const int u = (r / unit_rows) * a.n_kv_heads + h;
+    // first block whose range reaches into unit u: the smallest b with (unit[b+1], tile[b+1]) > (u, 0)
+    int lo = 0, hi = plan.nb - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const bool reaches = plan.unit[mid + 1] > u || (plan.unit[mid + 1] == u && plan.tile[mid + 1] > 0);
+        if (reaches) hi = mid;
+        else lo = mid + 1;
+    }
+    int slices = 1;
+    while (lo + slices < plan.nb && plan.unit[lo + slices] == u && plan.tile[lo + slices] > 0) ++slices;
     float M = -INFINITY;
     for (int s = 0; s < slices; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
     const float ML2 = M * L2E;
@@ -1638,184 +1137,11 @@ __global__ void score_merge_stats_kernel(ScoreArgs a, int R, int64_t rows_total)
     stats[i] = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
 
-// ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------
-template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax_kernel(ScoreArgs a) {
-    constexpr int NWAVES = PB_WAVES;
-    constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
-    typedef ScoreCfg<D> C;
-    typedef typename Mfma32<T>::v8 v8;
-    // two query-row tile buffers + the (m_r, log l_r) pairs of their 128 rows.  As in pass A nothing but LDS-DMA touches
-    // global memory inside the loop: a register-destination load there makes the compiler wait on the counter that also
-    // holds the tile in flight.
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE_BYTES + 2 * SC_TILE * 8];
-    char* const lstat = lds + 2 * C::TILE_BYTES;
-
-    // XCD-aware block order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The blocks that stream the SAME
-    // query-row tiles (same row slice and head, different ctx-key tile) get ids that are congruent mod 8 whenever
-    // row_splits*Hkv is a multiple of 8, so each query tile is fetched into ONE L2 instead of eight.
-    const int SH = a.row_splits * a.n_kv_heads;
-    const int bj = blockIdx.x % SH;            // (row slice, head)
-    const int ctile = blockIdx.x / SH;         // ctx-key tile
-    const int ysplit = bj % a.row_splits;
-    const int h = bj / a.row_splits;
-    const int R = a.G * a.q_len;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-
-    // stationary operand: 32 ctx keys per wave as the A operand (result row = key, 16 keys per lane)
-    const int j0 = ctile * SC_COLS + wave * 32;
-    v8 ak[C::KK];
-    {
-        const int j = min(j0 + l31, a.m - 1);
-        const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + j) * D) * 2 + half * 16;
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk)
-            ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for these loads belongs here
-    }
-    // this block's slice of the query rows (tiles of 128); the host picks row_splits so that no slice is empty
-    const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
-    const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
-    const int t_begin = ysplit * per;
-    const int t_end = min(total_tiles, t_begin + per);
-
-    const char* qbase = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * a.q_head_stride * 2;
-    auto rowptr = [&](int r) -> const char* {
-        r = min(r, R - 1);
-        const int g = r / a.q_len;
-        const int qi = r - g * a.q_len;
-        return qbase + ((int64_t)g * a.q_head_stride + (int64_t)qi * D) * 2;
-    };
-    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
-    // stage query-row tile t: linear when its 128 rows belong to one query head of the group
-    // merged statistics (m_r, log l_r); the array is padded to whole tiles with (+inf, 0): one 1-KiB DMA per tile
-    const char* stats_h = reinterpret_cast<const char*>(a.stats + (int64_t)h * a.stats_stride);
-    auto stage = [&](int b, int t) {
-        char* dst = lds + b * C::TILE_BYTES;
-        if (wave == 0) lds_dma16(stats_h + (int64_t)t * SC_TILE * 8 + lane * 16, lstat + b * SC_TILE * 8);
-        const int r0 = t * SC_TILE, r1 = r0 + SC_TILE - 1;
-        const int g0 = r0 / a.q_len;
-        const int qi0 = r0 - g0 * a.q_len;
-        if (r1 < R && qi0 + SC_TILE <= a.q_len)
-            stage_tile_linear<D, NWAVES>(dst, qbase + ((int64_t)g0 * a.q_head_stride + (int64_t)qi0 * D) * 2, lane_off, wave);
-        else
-            stage_tile<D, NWAVES>(dst, r0, rowptr, wave, lane);
-    };
-    auto load_frags = [&](u32x4 (&fr)[C::KK], const char* buf, int kb) {
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk)
-            fr[kk] = *reinterpret_cast<const u32x4*>(buf + C::lds_off(kb * 32 + l31, kk * 2 + half));
-    };
-
-    float best[16], hold[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) best[i] = -INFINITY;
-
-    // one 128-row tile = 4 blocks of 32 query rows; log-softmax t = (x - m_r) - log l_r, running maximum per key.
-    // Two blocks share one v_max3_f32 per key.
-    auto tile_body = [&](int b) {
-        const char* buf = lds + b * C::TILE_BYTES;
-        u32x4 fr[C::KK];
-        load_frags(fr, buf, 0);
-        float2 st[SC_TILE / 32];  // this lane's query row in each of the four 32-row blocks of the tile
-#pragma unroll
-        for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = *reinterpret_cast<const float2*>(lstat + (b * SC_TILE + kb * 32 + l31) * 8);
-#pragma unroll
-        for (int kb = 0; kb < SC_TILE / 32; ++kb) {
-            f16v acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[kk]), acc);
-            if (kb + 1 < SC_TILE / 32) load_frags(fr, buf, kb + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const float neg_mr = -st[kb].x, ll = st[kb].y;
-            uint32_t xp[8];
-            float av[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) av[i] = acc[i];
-            chain_block<T, FAST, false>(av, xp, a.c, a.rcp);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float t0 = pair_sub<T, 0>(xp[p], neg_mr) - ll;
-                const float t1 = pair_sub<T, 1>(xp[p], neg_mr) - ll;
-                if (kb & 1) {
-                    best[2 * p] = fmaxf(fmaxf(best[2 * p], hold[2 * p]), t0);
-                    best[2 * p + 1] = fmaxf(fmaxf(best[2 * p + 1], hold[2 * p + 1]), t1);
-                } else {
-                    hold[2 * p] = t0;
-                    hold[2 * p + 1] = t1;
-                }
-            }
-        }
-    };
-
-    if (t_begin < t_end) {
-        stage(0, t_begin);
-        stage_wait();
-        block_barrier();
-        // two tiles per trip: both buffers have compile-time addresses
-        for (int t = t_begin; t < t_end; t += 2) {
-            if (t + 1 < t_end) stage(1, t + 1);
-            tile_body(0);
-            stage_wait();
-            block_barrier();  // next tile landed and everybody is done reading this one
-            if (t + 1 >= t_end) break;
-            if (t + 2 < t_end) stage(0, t + 2);
-            tile_body(1);
-            stage_wait();
-            block_barrier();
-        }
-    }
-    // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float b = best[i];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
-        best[i] = b;
-    }
-    if (l31 == 0) {
-        float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (j < a.m) dst[j] = best[i];
-        }
-    }
-}
 
 // ---- pass B, software-pipelined form (round 2): the matrix chain of 32-row block b+1 rides inside the epilogue of block b -----
 // (same tiling and staging as score_colmax_kernel).  Epilogue of four logits: one assembly block with the rounding chain and
 // x - m_r (8 instructions, see quad_args), one with - log l_r and the running maxima; blocks alternate between "hold" and
 // "v_max3(best, hold, t)" so that two blocks share one maximum instruction per key.
-__device__ static inline void quad_hold(const float (&t)[4], float ll, float& h0, float& h1, float& h2, float& h3) {
-    asm("v_sub_f32 %[h0], %[t0], %[ll]\n\t"
-        "v_sub_f32 %[h1], %[t1], %[ll]\n\t"
-        "v_sub_f32 %[h2], %[t2], %[ll]\n\t"
-        "v_sub_f32 %[h3], %[t3], %[ll]"
-        : [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3)
-        : [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]), [ll] "v"(ll));
-}
-__device__ static inline void quad_max(float (&t)[4], float ll, float& b0, float& b1, float& b2, float& b3, float h0, float h1,
-                                       float h2, float h3) {
-    asm("v_sub_f32 %[t0], %[t0], %[ll]\n\t"
-        "v_sub_f32 %[t1], %[t1], %[ll]\n\t"
-        "v_sub_f32 %[t2], %[t2], %[ll]\n\t"
-        "v_sub_f32 %[t3], %[t3], %[ll]\n\t"
-        "v_max3_f32 %[b0], %[b0], %[h0], %[t0]\n\t"
-        "v_max3_f32 %[b1], %[b1], %[h1], %[t1]\n\t"
-        "v_max3_f32 %[b2], %[b2], %[h2], %[t2]\n\t"
-        "v_max3_f32 %[b3], %[b3], %[h3], %[t3]"
-        : [t0] "+v"(t[0]), [t1] "+v"(t[1]), [t2] "+v"(t[2]), [t3] "+v"(t[3]), [b0] "+v"(b0), [b1] "+v"(b1), [b2] "+v"(b2),
-          [b3] "+v"(b3)
-        : [h0] "v"(h0), [h1] "v"(h1), [h2] "v"(h2), [h3] "v"(h3), [ll] "v"(ll));
-}
-
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
@@ -1913,13 +1239,9 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
                         auto&& hook) __attribute__((always_inline)) {
             constexpr bool ODD = decltype(odd_tag)::value;
             constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
-#if KVZ_PB_FUSED_SUB
             // x - (m_r + log l_r): the two per-row statistics are added once per step and lane, the subtraction rides in the fma
             // of the rounding chain (48 + 8 instead of 48 + 16 + 8 VALU instructions per 32x32 block)
             const float neg_mr = -(st.x + st.y);
-#else
-            const float neg_mr = -st.x, ll = st.y;
-#endif
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 float tv[4];
@@ -1941,7 +1263,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
                         accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), accn);
                     }
                 }
-#if KVZ_PB_FUSED_SUB
                 if constexpr (ODD) {
                     // (outputs NOT tied to the inputs: the allocator answered "+v" on the loop-carried maxima with a register copy
                     // per maximum and step; left to the compiler as plain fmaxf the maxima drift away from their block and spill)
@@ -1957,13 +1278,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hold[4 * qd + j] = tv[j];  // (a renaming: the chain wrote the held values)
                 }
-#else
-                if constexpr (ODD)
-                    quad_max(tv, ll, best[4 * qd], best[4 * qd + 1], best[4 * qd + 2], best[4 * qd + 3], hold[4 * qd], hold[4 * qd + 1],
-                             hold[4 * qd + 2], hold[4 * qd + 3]);
-                else
-                    quad_hold(tv, ll, hold[4 * qd], hold[4 * qd + 1], hold[4 * qd + 2], hold[4 * qd + 3]);
-#endif
                 if (qd == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     hook();
@@ -2067,11 +1381,6 @@ __global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int6
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// key slices of pass A
-static inline int score_key_splits(int sink, int m, int q_len) {
-    const int ntiles = (sink + m + q_len + SC_TILE - 1) / SC_TILE;
-    return (ntiles + SC_KSPLIT_TILES - 1) / SC_KSPLIT_TILES;
-}
 // number of row slices of pass B: enough blocks to fill 256 CUs about twice, no empty slice
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
     const int ctiles = (m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
@@ -2174,24 +1483,6 @@ template <typename T, int D, bool FAST>
 static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     const int R = a.G * a.q_len;
     a.n_kv_heads = Hkv;
-#if KVZ_PA_V3
-    {
-        PaPlan plan;
-        if (!p3_make_plan(plan, a.sink, a.m, a.q_len, a.G, Hkv)) {
-            set_error("kvz_score_chunk: more than 65535 (head, 512-row tile) units");
-            return KVZ_EUNSUPPORTED;
-        }
-        {
-            ProfScope ps("score_rowstat", stream);
-            hipLaunchKernelGGL((score_rowstat3_kernel<T, D, FAST>), dim3(plan.nb), dim3(P3_WAVES * 64), 0, stream, a, plan);
-        }
-        KVZ_CHECK_LAUNCH("score_rowstat3_kernel");
-        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
-        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total, P3_ROWS);
-        KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
-    }
-#else
-#if KVZ_PA_V2 && KVZ_PA_PLAN
     {
         PaPlan plan;
         if (!make_plan(plan, PA_ROWS, a.sink, a.m, a.q_len, a.G, Hkv)) {
@@ -2207,35 +1498,11 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total, PA_ROWS);
         KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
     }
-#else
-    {
-        const int items = (R + PA_ROWS - 1) / PA_ROWS * Hkv * a.key_splits;
-        const int blocks = min(items, SC_PERSISTENT_BLOCKS);
-        ProfScope ps("score_rowstat", stream);
-#if KVZ_PA_V2
-        PaPlan plan{};
-        hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a, plan);
-#else
-        hipLaunchKernelGGL((score_rowstat_kernel<T, D, FAST>), dim3(blocks), dim3(PA_WAVES * 64), 0, stream, a);
-#endif
-    }
-    KVZ_CHECK_LAUNCH("score_rowstat_kernel");
-    {
-        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
-        hipLaunchKernelGGL(score_merge_stats_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, R, rows_total);
-    }
-    KVZ_CHECK_LAUNCH("score_merge_stats_kernel");
-#endif
-#endif
     const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     {
         ProfScope ps("score_colmax", stream);
-#if KVZ_PB_V2
         hipLaunchKernelGGL((score_colmax2_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
-#else
-        hipLaunchKernelGGL((score_colmax_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
-#endif
     }
     KVZ_CHECK_LAUNCH("score_colmax_kernel");
     if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
@@ -2256,14 +1523,9 @@ using namespace kvz;
 
 static inline int score_stats_stride(int G, int q_len) { return (G * q_len + SC_TILE - 1) / SC_TILE * SC_TILE; }
 static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
-    int slices = score_key_splits(sink, m, q_len);
-#if KVZ_PA_V3
-    PaPlan plan;  // one partial per block that touches a 512-row tile
-    if (p3_make_plan(plan, sink, m, q_len, G, Hkv) && plan.max_seg > slices) slices = plan.max_seg;
-#elif KVZ_PA_V2 && KVZ_PA_PLAN
+    int slices = 1;
     PaPlan plan;  // one partial per block that touches a row tile
-    if (make_plan(plan, PA_ROWS, sink, m, q_len, G, Hkv) && plan.max_seg > slices) slices = plan.max_seg;
-#endif
+    if (make_plan(plan, PA_ROWS, sink, m, q_len, G, Hkv)) slices = plan.max_seg;
     return align256((size_t)slices * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
 }
 
@@ -2324,7 +1586,6 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
                             kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && (out || log_out) && ws, KVZ_EINVAL, "kvz_score_chunk: null pointer");
-    KVZ_REQUIRE(log_out == nullptr || KVZ_PB_V2, KVZ_EUNSUPPORTED, "kvz_score_chunk_log: this build uses the round-1 column kernel");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
     KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_score_chunk: head_dim %d unsupported (64 or 128)", D);
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_score_chunk: bad dtype %d", dtype);
@@ -2342,14 +1603,12 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.q = q; a.k = k; a.q_head_stride = q_head_stride; a.k_head_stride = k_head_stride;
     a.klen = klen; a.sink = sink; a.start = start; a.m = m; a.q_len = q_len; a.G = G;
     a.stats = reinterpret_cast<float2*>(ws);
-    a.key_splits = score_key_splits(sink, m, q_len);
     a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.out = out; a.out_head_stride = out_head_stride;
     a.log_out = log_out; a.log_head_stride = log_head_stride;
     a.dq = make_fastdiv(q_len);
     a.dh = make_fastdiv(Hkv);
-    a.dz = make_fastdiv((G * q_len + PA_ROWS - 1) / PA_ROWS * Hkv);
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
     a.rcp = find_exact_reciprocal(D, dtype);
     if (dtype == KVZ_F16) {
@@ -2410,7 +1669,7 @@ extern "C" int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, 
     KVZ_REQUIRE(unit && tile && n_blocks && max_seg && rows_per_unit, KVZ_EINVAL, "kvz_debug_score_plan: null pointer");
     KVZ_REQUIRE(sink >= 0 && m > 0 && q_len > 0 && G > 0 && Hkv > 0, KVZ_EINVAL, "kvz_debug_score_plan: bad shape");
     PaPlan p;
-    const int rows = KVZ_PA_V3 ? P3_ROWS : PA_ROWS;
+    const int rows = PA_ROWS;
     KVZ_REQUIRE(make_plan(p, rows, sink, m, q_len, G, Hkv), KVZ_EUNSUPPORTED, "kvz_debug_score_plan: too many units");
     for (int b = 0; b <= PLAN_MAX_BLOCKS; ++b) { unit[b] = p.unit[b]; tile[b] = p.tile[b]; }
     *n_blocks = p.nb;
