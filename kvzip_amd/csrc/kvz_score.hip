@@ -26,6 +26,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
+#include <vector>
 #include <type_traits>
 
 namespace kvz {
@@ -36,9 +38,17 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Mfma32;
+// mfma_a* / mfma_b*: MFMA issued from assembly with the STATIONARY fragment (B operand in pass A, A operand in pass B) in ACCUMULATOR
+// registers ("a") and the result in ordinary VGPRs.  The one-wave-per-SIMD builds (KVZ_PA_WAVES = 4 / KVZ_PB_WAVES = 4, 512 registers
+// per lane) use them to keep the 64 stationary fragment registers out of the 256 VGPRs the VALU chain works in; left alone the
+// allocator puts the ACCUMULATORS into the AGPRs and copies all 16 values of every block back with v_accvgpr_read.
 template <> struct Mfma32<_Float16> {
     typedef h8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static inline void mfma_a0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b)); }
+    __device__ static inline void mfma_a(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b)); }
+    __device__ static inline void mfma_b0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b)); }
+    __device__ static inline void mfma_b(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); }
     // first MFMA of a chain (C = 0) written INTO the registers of `acc`: the tied operand keeps an accumulator in one physical
     // register tuple for the whole kernel (left to the allocator every chain is a fresh 16-tuple, and under pressure the hunt
     // for free aligned tuples spills the fragment registers).  No software wait states are needed after it: the next MFMA of
@@ -50,6 +60,10 @@ template <> struct Mfma32<_Float16> {
 template <> struct Mfma32<__bf16> {
     typedef b8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static inline void mfma_a0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b)); }
+    __device__ static inline void mfma_a(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b)); }
+    __device__ static inline void mfma_b0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b)); }
+    __device__ static inline void mfma_b(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); }
     __device__ static inline void mfma_first(f16v& acc, v8 a, v8 b) {
         asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "v"(b));
     }
@@ -58,7 +72,12 @@ template <> struct Mfma32<__bf16> {
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
 #ifndef KVZ_PB_WAVES
 #define KVZ_PB_WAVES 8   // round 2: one 8-wave block per CU (three 32-KiB row-tile buffers; 4 LDS-DMA pieces per wave and tile)
-#define KVZ_PB_OCC 2
+#endif
+#ifndef KVZ_PB_OCC
+#define KVZ_PB_OCC (KVZ_PB_WAVES / 4)
+#endif
+#ifndef KVZ_PB_AGPR
+#define KVZ_PB_AGPR (KVZ_PB_WAVES == 4)   // stationary keys of pass B in accumulator registers
 #endif
 constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
 constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
@@ -93,6 +112,7 @@ struct ScoreArgs {
     void* out;           // [Hkv, m] half
     int64_t out_head_stride;
     int row_splits;      // pass B
+    int unit_rows;       // rows per unit of the pass-A partition (PA_ROWS)
     int n_kv_heads;
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
@@ -278,7 +298,12 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 //    has been issued, not after its epilogue.  The tile stream runs across item boundaries.
 #ifndef KVZ_PA_WAVES
 #define KVZ_PA_WAVES 8
+#endif
+#ifndef KVZ_PA_RG
 #define KVZ_PA_RG 1
+#endif
+#ifndef KVZ_PA_AGPR
+#define KVZ_PA_AGPR (KVZ_PA_WAVES == 4)   // query rows of pass A in accumulator registers
 #endif
 constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
@@ -763,7 +788,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
     for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
+        for (int kk = 0; kk < C::KK; ++kk) {
+#if KVZ_PA_AGPR
+            asm volatile("" : "+a"(bq[g][kk]));  // the rows are in (accumulator) registers: the area is free
+#else
+            asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
+#endif
+        }
     if (valid(nxt)) stage_q(nxt);
     Rows rows = rows_of(cur);
 
@@ -832,7 +863,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL & 4
                         accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
 #else
+#if KVZ_PA_AGPR
+                        if (kk == 0) Mfma32<T>::mfma_a0(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
+                        else Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
+#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
+#endif
 #endif
                     }
             }
@@ -862,7 +898,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL & 4
                         accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
 #else
+#if KVZ_PA_AGPR
+                        Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
+#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], accn[g]);
+#endif
 #endif
                     }
             }
@@ -913,7 +953,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
             for (int g = 0; g < PA_RG; ++g)
+#if KVZ_PA_AGPR
+                if (kk == 0) Mfma32<T>::mfma_a0(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
+                else Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
+#else
                 accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -1078,7 +1123,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
-            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));  // rows in registers: the area is free again
+#if KVZ_PA_AGPR
+            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+a"(bq[g][kk]));   // ... and move to the accumulator file
+#else
+            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));
+#endif  // rows in registers: the area is free again
         KVZ_STAMP(10);
         chain0(acc[0], fr[0]);  // (the eight dependent MFMAs run under the index arithmetic below)
         KVZ_STAMP(11);
@@ -1102,19 +1151,40 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     }
 }
 
-// merge of the partial statistics:  stats[0] <- (m_r, log l_r); a row tile has one partial per block that touched it
-__global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64_t rows_total, int unit_rows) {
+// ---- pass B: per-ctx-key maximum of the log-softmax over all query rows --------------------------------------------------
+// ctx keys are the STATIONARY A operand (PB_RG groups of 32 per wave), query-row tiles stream through the three-buffer LDS ring
+// and the query row is again the lane; the matrix chain of 32-row block b+1 rides inside the epilogue of block b (same in-wave
+// pipeline as pass A).  Epilogue of four logits: one assembly block with the rounding chain and x - (m_r + log l_r) (see
+// quad_args); blocks alternate between "hold" and "v_max3(best, hold, t)" so that two blocks share one maximum per key.
+// Round 3: the partial statistics of pass A are merged in the PROLOGUE of this kernel (each block merges the segments of its own
+// row slice into LDS: bit-identical to the former merge launch, which is gone together with the per-tile statistics DMA).
+#ifndef KVZ_PB_RG
+#define KVZ_PB_RG 1
+#endif
+constexpr int PB_RG = KVZ_PB_RG;                 // groups of 32 stationary keys per wave
+#ifndef KVZ_PB_HOLD
+#define KVZ_PB_HOLD (KVZ_PB_RG == 1)             // 1: even blocks hold their values, odd blocks fold both with one v_max3 per key
+#endif
+constexpr bool PB_HOLD = KVZ_PB_HOLD;
+constexpr int PB_COLS = PB_WAVES * PB_RG * 32;   // stationary ctx keys per block
+constexpr int PB_STAT_TILES = 56;                // row tiles per block whose merged statistics fit beside the ring (56 KiB)
+
+// merged statistics (m_r, log l_r) of row r of KV head h from the partials of pass A; rows >= R: (+inf, 0) = never a maximum
+__device__ static inline float2 merge_row_stats(const float2* __restrict__ stats, int64_t rows_total, int64_t i, int slices) {
     constexpr float L2E = 1.44269504088896340736f;
-    float2* __restrict__ stats = a.stats;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [Hkv, stats_stride]
-    if (i >= rows_total) return;
-    const int r = (int)(i % a.stats_stride);
-    const int h = (int)(i / a.stats_stride);
-    if (r >= R) {
-        stats[i] = make_float2(INFINITY, 0.f);
-        return;
+    float M = -INFINITY;
+    for (int s = 0; s < slices; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
+    const float ML2 = M * L2E;
+    float Lp = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const float2 ps = stats[s * rows_total + i];
+        Lp += ps.y * __builtin_amdgcn_exp2f(ps.x * L2E - ML2);
     }
-    const int u = (r / unit_rows) * a.n_kv_heads + h;
+    const float delta = __builtin_fmaf(M, L2E, -ML2);
+    return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
+}
+// number of blocks of pass A that touched unit u (= partial statistics per row of the unit)
+__device__ static inline int plan_unit_slices(const PaPlan& plan, int u) {
     // first block whose range reaches into unit u: the smallest b with (unit[b+1], tile[b+1]) > (u, 0)
     int lo = 0, hi = plan.nb - 1;
     while (lo < hi) {
@@ -1125,33 +1195,20 @@ __global__ void score_merge_stats3_kernel(ScoreArgs a, PaPlan plan, int R, int64
     }
     int slices = 1;
     while (lo + slices < plan.nb && plan.unit[lo + slices] == u && plan.tile[lo + slices] > 0) ++slices;
-    float M = -INFINITY;
-    for (int s = 0; s < slices; ++s) M = fmaxf(M, stats[s * rows_total + i].x);
-    const float ML2 = M * L2E;
-    float Lp = 0.f;
-    for (int s = 0; s < slices; ++s) {
-        const float2 ps = stats[s * rows_total + i];
-        Lp += ps.y * __builtin_amdgcn_exp2f(ps.x * L2E - ML2);
-    }
-    const float delta = __builtin_fmaf(M, L2E, -ML2);
-    stats[i] = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
+    return slices;
 }
 
-
-// ---- pass B, software-pipelined form (round 2): the matrix chain of 32-row block b+1 rides inside the epilogue of block b -----
-// (same tiling and staging as score_colmax_kernel).  Epilogue of four logits: one assembly block with the rounding chain and
-// x - m_r (8 instructions, see quad_args), one with - log l_r and the running maxima; blocks alternate between "hold" and
-// "v_max3(best, hold, t)" so that two blocks share one maximum instruction per key.
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a, PaPlan plan) {
     constexpr int NWAVES = PB_WAVES;
-    constexpr int SC_COLS = NWAVES * 32;  // stationary ctx keys per block (32 per wave)
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     constexpr int RING = 3;  // query-row tile p of the block's slice lives in buffer p % 3 (see score_rowstat2_kernel)
-    __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + RING * SC_TILE * 8];
-    char* const lstat = lds + RING * C::TILE_BYTES;
-    constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile (+1 for wave 0: statistics)
+    constexpr int MAX_UNITS = PB_STAT_TILES * SC_TILE / 32 + 2;  // units (>= 32 rows each) a row slice can reach into
+    __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + PB_STAT_TILES * SC_TILE * 8];
+    __shared__ int unit_slices[MAX_UNITS];
+    float2* const lstat = reinterpret_cast<float2*>(lds + RING * C::TILE_BYTES);
+    constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
@@ -1167,15 +1224,16 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
-    // stationary operand: 32 ctx keys per wave as the A operand (result row = key, 16 keys per lane)
-    const int j0 = ctile * SC_COLS + wave * 32;
-    v8 ak[C::KK];
-    {
-        const int j = min(j0 + l31, a.m - 1);
+    // stationary operand: 32 ctx keys per group as the A operand (result row = key, 16 keys per lane)
+    const int j0 = ctile * PB_COLS + wave * PB_RG * 32;
+    v8 ak[PB_RG][C::KK];
+#pragma unroll
+    for (int g = 0; g < PB_RG; ++g) {
+        const int j = min(j0 + g * 32 + l31, a.m - 1);
         const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + j) * D) * 2 + half * 16;
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk)
-            ak[kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
+            ak[g][kk] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(kp + kk * 32));
     }  // (no wait here: the first two row tiles are staged while these loads are in flight)
     const int total_tiles = (R + SC_TILE - 1) / SC_TILE;
     const int per = (total_tiles + a.row_splits - 1) / a.row_splits;
@@ -1190,7 +1248,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
         return qbase + ((int64_t)g * a.q_head_stride + (int64_t)qi * D) * 2;
     };
     const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
-    const char* stats_h = reinterpret_cast<const char*>(a.stats + (int64_t)h * a.stats_stride);
     const uint32_t lds0 = lds_addr(lds);
     // staging cursor: tiles are staged in order, so the (query head, row in head) of a tile's first row is advanced
     // incrementally (one scalar division per block instead of one per tile)
@@ -1198,7 +1255,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
     auto stage = [&](int b) __attribute__((always_inline)) {  // stages tile sg_t into buffer b and advances the cursor
         const int t = sg_t;
         const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
-        if (wave == 0) lds_dma16a(stats_h + (int64_t)t * SC_TILE * 8, (uint32_t)(lane * 16), lds0 + (uint32_t)(RING * C::TILE_BYTES + b * SC_TILE * 8));
         const int r0 = t * SC_TILE;
         if (r0 + SC_TILE <= R && sg_qi + SC_TILE <= a.q_len) {
             stage_tile_linear_a<D, NWAVES>(dst, qbase + ((int64_t)sg_g * a.q_head_stride + (int64_t)sg_qi * D) * 2, lane_off, wave);
@@ -1215,68 +1271,109 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
         frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
     };
 
-    float best[16], hold[16];
+    float best[PB_RG][16], hold[PB_RG][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) best[i] = hold[i] = -INFINITY;
+    for (int g = 0; g < PB_RG; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) best[g][i] = hold[g][i] = -INFINITY;
 
     if (t_begin < t_end) {
         stage(0);
         if (t_begin + 1 < t_end) stage(1);
+        // ---- merged statistics of the block's row slice -> LDS (the first two tiles are in flight meanwhile) ----
+        {
+            const int row_lo = t_begin * SC_TILE, nrows = (t_end - t_begin) * SC_TILE;
+            const int u_lo = row_lo / a.unit_rows, u_hi = min(R - 1, row_lo + nrows - 1) / a.unit_rows;
+            for (int uu = threadIdx.x; uu <= u_hi - u_lo; uu += NWAVES * 64)
+                unit_slices[uu] = plan_unit_slices(plan, (u_lo + uu) * a.n_kv_heads + h);
+            __syncthreads();
+            const int64_t rows_total = (int64_t)a.n_kv_heads * a.stats_stride;
+            for (int idx = threadIdx.x; idx < nrows; idx += NWAVES * 64) {
+                const int r = row_lo + idx;
+                float2 v = make_float2(INFINITY, 0.f);
+                if (r < R) v = merge_row_stats(a.stats, rows_total, (int64_t)h * a.stats_stride + r, unit_slices[r / a.unit_rows - u_lo]);
+                lstat[idx] = v;
+            }
+        }
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(ak[kk]));  // the wait for the stationary keys belongs here
+        for (int g = 0; g < PB_RG; ++g)
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) {
+#if KVZ_PB_AGPR
+                asm volatile("" : "+a"(ak[g][kk]));  // the wait for the stationary keys belongs here (... and they move to the accumulator file)
+#else
+                asm volatile("" : "+v"(ak[g][kk]));  // the wait for the stationary keys belongs here
+#endif
+            }
         stage_wait();
         block_barrier();
         u32x4 fr[2][C::KK];
         load_frags(fr[0], I0{}, I0{});
         load_frags(fr[1], I0{}, I1{});
-        f16v acc[2];
+        f16v acc[2][PB_RG];
         const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int t = t_begin;
+        auto mfma_step = [&](f16v (&accn)[PB_RG], const u32x4 (&frn)[C::KK], int kk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < PB_RG; ++g) {
+#if KVZ_PB_AGPR
+                if (kk == 0) Mfma32<T>::mfma_b0(accn[g], ak[g][kk], __builtin_bit_cast(v8, frn[kk]));
+                else Mfma32<T>::mfma_b(accn[g], ak[g][kk], __builtin_bit_cast(v8, frn[kk]));
+#else
+                accn[g] = Mfma32<T>::mfma(ak[g][kk], __builtin_bit_cast(v8, frn[kk]), kk == 0 ? zero16 : accn[g]);
+#endif
+            }
+        };
 
         // one pipeline step: chain of the next block (frn -> accn) inside the epilogue of the current block (accc); ODD blocks
         // fold the held values of the previous block and their own into the running maxima
-        auto step = [&](f16v& accn, const f16v& accc, const u32x4 (&frn)[C::KK], float2 st, auto odd_tag, auto mfma_tag,
+        auto step = [&](f16v (&accn)[PB_RG], const f16v (&accc)[PB_RG], const u32x4 (&frn)[C::KK], float2 st, auto odd_tag,
                         auto&& hook) __attribute__((always_inline)) {
             constexpr bool ODD = decltype(odd_tag)::value;
-            constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
             // x - (m_r + log l_r): the two per-row statistics are added once per step and lane, the subtraction rides in the fma
-            // of the rounding chain (48 + 8 instead of 48 + 16 + 8 VALU instructions per 32x32 block)
+            // of the rounding chain
             const float neg_mr = -(st.x + st.y);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                float tv[4];
-                uint32_t xa, xb;
+                float tv[PB_RG][4];
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (WITH_MFMA) {
 #pragma unroll
-                    for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd); ++c) {
-                        const int kk = MfmaSched<C::KK>::first(2 * qd) + c;
-                        accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), kk == 0 ? zero16 : accn);
-                    }
+                for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd); ++c) mfma_step(accn, frn, MfmaSched<C::KK>::first(2 * qd) + c);
+#pragma unroll
+                for (int g = 0; g < PB_RG; ++g) {
+                    uint32_t xa, xb;
+                    quad_args<T, FAST>(accc[g][4 * qd], accc[g][4 * qd + 1], accc[g][4 * qd + 2], accc[g][4 * qd + 3], xa, xb, tv[g], a.c, a.rcp,
+                                       1.0f, neg_mr);
                 }
-                quad_args<T, FAST>(accc[4 * qd], accc[4 * qd + 1], accc[4 * qd + 2], accc[4 * qd + 3], xa, xb, tv, a.c, a.rcp, 1.0f, neg_mr);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (WITH_MFMA) {
 #pragma unroll
-                    for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd + 1); ++c) {
-                        const int kk = MfmaSched<C::KK>::first(2 * qd + 1) + c;
-                        accn = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, frn[kk]), accn);
+                for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd + 1); ++c) mfma_step(accn, frn, MfmaSched<C::KK>::first(2 * qd + 1) + c);
+#pragma unroll
+                for (int g = 0; g < PB_RG; ++g) {
+                    if constexpr (!PB_HOLD) {
+                        // (two groups per wave: the 32 held registers do not fit beside 64 accumulators and 64 fragment registers -
+                        // one plain maximum per logit, 2.5 cycles each instead of 4.2 per pair)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float nb;
+                            asm("v_max_f32 %0, %1, %2" : "=v"(nb) : "v"(best[g][4 * qd + j]), "v"(tv[g][j]));
+                            best[g][4 * qd + j] = nb;
+                        }
+                    } else if constexpr (ODD) {
+                        // (outputs NOT tied to the inputs: the allocator answered "+v" on the loop-carried maxima with a register copy
+                        // per maximum and step; left to the compiler as plain fmaxf the maxima drift away from their block and spill)
+                        // (one instruction per statement: an output without early-clobber may share a register with an input of
+                        // its OWN instruction only)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float nb;
+                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(nb) : "v"(best[g][4 * qd + j]), "v"(hold[g][4 * qd + j]), "v"(tv[g][j]));
+                            best[g][4 * qd + j] = nb;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hold[g][4 * qd + j] = tv[g][j];  // (a renaming: the chain wrote the held values)
                     }
-                }
-                if constexpr (ODD) {
-                    // (outputs NOT tied to the inputs: the allocator answered "+v" on the loop-carried maxima with a register copy
-                    // per maximum and step; left to the compiler as plain fmaxf the maxima drift away from their block and spill)
-                    // (one instruction per statement: an output without early-clobber may share a register with an input of
-                    // its OWN instruction only)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float nb;
-                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(nb) : "v"(best[4 * qd + j]), "v"(hold[4 * qd + j]), "v"(tv[j]));
-                        best[4 * qd + j] = nb;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hold[4 * qd + j] = tv[j];  // (a renaming: the chain wrote the held values)
                 }
                 if (qd == 0) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1289,17 +1386,17 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
             constexpr int B = decltype(b_tag)::value;
             constexpr int B1 = (B + 1) % RING, B2 = (B + 2) % RING;
             float2 st[SC_TILE / 32];  // (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of the tile
+            const float2* const ls = lstat + (t - t_begin) * SC_TILE + l31;
 #pragma unroll
-            for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = *reinterpret_cast<const float2*>(lstat + (B * SC_TILE + kb * 32 + l31) * 8);
-            step(acc[1], acc[0], fr[1], st[0], std::false_type{}, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
-            step(acc[0], acc[1], fr[0], st[1], std::true_type{}, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
-            step(acc[1], acc[0], fr[1], st[2], std::false_type{}, std::true_type{}, [&]() __attribute__((always_inline)) {
+            for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = ls[kb * 32];
+            step(acc[1], acc[0], fr[1], st[0], std::false_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
+            step(acc[0], acc[1], fr[0], st[1], std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+            step(acc[1], acc[0], fr[1], st[2], std::false_type{}, [&]() __attribute__((always_inline)) {
                 // hand-over: the tile two positions ahead goes into the buffer the previous hand-over freed, its DMA is issued
                 // BEFORE the barrier; the counted wait leaves exactly those pieces in flight
                 if (t + 2 < t_end) {
                     stage(B2);
-                    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + 1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
                 } else {
                     stage_wait();
                 }
@@ -1307,52 +1404,63 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax2_kernel(Sc
                 if (t + 1 < t_end) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
             });
             // (after the last tile the chain issued here is not used)
-            step(acc[0], acc[1], fr[0], st[3], std::true_type{}, std::true_type{}, [&]() __attribute__((always_inline)) {
+            step(acc[0], acc[1], fr[0], st[3], std::true_type{}, [&]() __attribute__((always_inline)) {
                 if (t + 1 < t_end) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
             });
         };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) acc[0] = Mfma32<T>::mfma(ak[kk], __builtin_bit_cast(v8, fr[0][kk]), kk == 0 ? zero16 : acc[0]);
+        for (int kk = 0; kk < C::KK; ++kk) mfma_step(acc[0], fr[0], kk);
         __builtin_amdgcn_sched_barrier(0);
-        for (int pb = 0; t < t_end; ++t, pb = (pb == RING - 1) ? 0 : pb + 1) {
-            if (pb == 0) tile_steps(I0{});
-            else if (pb == 1) tile_steps(I1{});
-            else tile_steps(I2{});
+        // (the three ring positions follow each other in program order - one loop back-edge instead of three: a dispatch on the
+        // ring position makes the allocator reconcile the registers of the 32-64 running maxima at the end of every variant)
+        while (true) {
+            tile_steps(I0{});
+            if (++t >= t_end) break;
+            tile_steps(I1{});
+            if (++t >= t_end) break;
+            tile_steps(I2{});
+            if (++t >= t_end) break;
         }
     }
     // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
+    // (lane id recomputed: values kept alive across the loop for this epilogue would cost registers - one of them spilled)
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int l31_e = lane_e & 31, half_e = lane_e >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        // all-reduce inside each row of 16 lanes with DPP (rotate by 8 and 4, then the two quad permutations: four VALU
-        // instructions, no LDS), one cross-row exchange through ds_bpermute
-        float b = best[i];
-        auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
-            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
-        };
-        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x128>{}));  // row_ror:8
-        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x124>{}));  // row_ror:4
-        b = fmaxf(b, dpp(b, std::integral_constant<int, 0x4E>{}));   // quad_perm:[2,3,0,1]
-        b = fmaxf(b, dpp(b, std::integral_constant<int, 0xB1>{}));   // quad_perm:[1,0,3,2]
-        b = fmaxf(b, __shfl_xor(b, 16, 64));
-        best[i] = b;
-    }
-    if (l31 == 0) {
-        if (a.log_out) {
-            // log-softmax values are <= 0 (clamped: rounding may leave +1e-7, and exp of either rounds to the same 16-bit 1.0), and
-            // for non-positive floats "larger" is "smaller bit pattern": the maximum over the row slices is an unsigned minimum
-            uint32_t* dst = a.log_out + (int64_t)h * a.log_head_stride;
+    for (int g = 0; g < PB_RG; ++g) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (j < a.m) atomicMin(dst + j, __builtin_bit_cast(uint32_t, fminf(best[i], 0.f)) | 0u);
-            }
-        } else {
-            float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+        for (int i = 0; i < 16; ++i) {
+            // all-reduce inside each row of 16 lanes with DPP (rotate by 8 and 4, then the two quad permutations: four VALU
+            // instructions, no LDS), one cross-row exchange through ds_bpermute
+            float b = best[g][i];
+            auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
+            };
+            b = fmaxf(b, dpp(b, std::integral_constant<int, 0x128>{}));  // row_ror:8
+            b = fmaxf(b, dpp(b, std::integral_constant<int, 0x124>{}));  // row_ror:4
+            b = fmaxf(b, dpp(b, std::integral_constant<int, 0x4E>{}));   // quad_perm:[2,3,0,1]
+            b = fmaxf(b, dpp(b, std::integral_constant<int, 0xB1>{}));   // quad_perm:[1,0,3,2]
+            b = fmaxf(b, __shfl_xor(b, 16, 64));
+            best[g][i] = b;
+        }
+        if (l31_e == 0) {
+            if (a.log_out) {
+                // log-softmax values are <= 0 (clamped: rounding may leave +1e-7, and exp of either rounds to the same 16-bit 1.0), and
+                // for non-positive floats "larger" is "smaller bit pattern": the maximum over the row slices is an unsigned minimum
+                uint32_t* dst = a.log_out + (int64_t)h * a.log_head_stride;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (j < a.m) dst[j] = best[i];
+                for (int i = 0; i < 16; ++i) {
+                    const int j = j0 + g * 32 + (i & 3) + 8 * (i >> 2) + 4 * half_e;
+                    if (j < a.m) atomicMin(dst + j, __builtin_bit_cast(uint32_t, fminf(best[g][i], 0.f)) | 0u);
+                }
+            } else {
+                float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int j = j0 + g * 32 + (i & 3) + 8 * (i >> 2) + 4 * half_e;
+                    if (j < a.m) dst[j] = best[g][i];
+                }
             }
         }
     }
@@ -1381,18 +1489,39 @@ __global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int6
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// number of row slices of pass B: enough blocks to fill 256 CUs about twice, no empty slice
+// number of row slices of pass B: enough blocks to fill 256 CUs once, no empty slice, and a slice's merged statistics fit LDS
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
-    const int ctiles = (m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
+    const int ctiles = (m + PB_COLS - 1) / PB_COLS;
     const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
 #ifndef KVZ_PB_BLOCKS
-#define KVZ_PB_BLOCKS (PB_WAVES == 8 ? 256 : 512)
+#define KVZ_PB_BLOCKS 256
 #endif
-    int splits = KVZ_PB_BLOCKS / (ctiles * Hkv);  // one round of resident blocks (1 or 2 per CU) when the shape allows
+    int splits = KVZ_PB_BLOCKS / (ctiles * Hkv);  // one round of resident blocks when the shape allows
+    const int need = (rtiles + PB_STAT_TILES - 1) / PB_STAT_TILES;
+    if (splits < need) splits = need;
     if (splits > rtiles) splits = rtiles;
     if (splits < 1) splits = 1;
     const int per = (rtiles + splits - 1) / splits;
     return (rtiles + per - 1) / per;
+}
+
+// the partition of pass A is a pure function of the shape: memoised (a scoring pass repeats two or three shapes thousands of
+// times, and the workspace check of every call needs max_seg as well)
+struct PlanKey { int sink, m, q_len, G, Hkv; };
+static bool get_plan(PaPlan& out, int sink, int m, int q_len, int G, int Hkv) {
+    static std::mutex mu;
+    static std::vector<std::pair<PlanKey, PaPlan>> cache;
+    static std::vector<PlanKey> bad;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : cache)
+        if (e.first.sink == sink && e.first.m == m && e.first.q_len == q_len && e.first.G == G && e.first.Hkv == Hkv) {
+            out = e.second;
+            return true;
+        }
+    if (!make_plan(out, PA_ROWS, sink, m, q_len, G, Hkv)) return false;
+    if (cache.size() >= 64) cache.erase(cache.begin());
+    cache.push_back({PlanKey{sink, m, q_len, G, Hkv}, out});
+    return true;
 }
 
 // ---- host: exhaustive search for an exact reciprocal constant ----------------------------------------------
@@ -1481,30 +1610,25 @@ static float find_exact_reciprocal_search(float c, int dtype) {
 
 template <typename T, int D, bool FAST>
 static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
-    const int R = a.G * a.q_len;
     a.n_kv_heads = Hkv;
-    {
-        PaPlan plan;
-        if (!make_plan(plan, PA_ROWS, a.sink, a.m, a.q_len, a.G, Hkv)) {
-            set_error("kvz_score_chunk: more than 65535 (head, row tile) units");
-            return KVZ_EUNSUPPORTED;
-        }
-        {
-            ProfScope ps("score_rowstat", stream);
-            hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
-        }
-        KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
-        const int64_t rows_total = (int64_t)Hkv * a.stats_stride;
-        hipLaunchKernelGGL(score_merge_stats3_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, stream, a, plan, R, rows_total, PA_ROWS);
-        KVZ_CHECK_LAUNCH("score_merge_stats3_kernel");
+    PaPlan plan;
+    if (!get_plan(plan, a.sink, a.m, a.q_len, a.G, Hkv)) {
+        set_error("kvz_score_chunk: more than 65535 (head, row tile) units");
+        return KVZ_EUNSUPPORTED;
     }
-    const int ctiles = (a.m + PB_WAVES * 32 - 1) / (PB_WAVES * 32);
+    a.unit_rows = PA_ROWS;
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     {
-        ProfScope ps("score_colmax", stream);
-        hipLaunchKernelGGL((score_colmax2_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+        ProfScope ps("score_rowstat", stream);
+        hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
     }
-    KVZ_CHECK_LAUNCH("score_colmax_kernel");
+    KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
+    const int ctiles = (a.m + PB_COLS - 1) / PB_COLS;
+    {
+        ProfScope ps("score_colmax", stream);
+        hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a, plan);
+    }
+    KVZ_CHECK_LAUNCH("score_colmax3_kernel");
     if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
                        a.row_splits, Hkv, a.m, reinterpret_cast<T*>(a.out), a.out_head_stride);
@@ -1525,7 +1649,7 @@ static inline int score_stats_stride(int G, int q_len) { return (G * q_len + SC_
 static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sink) {
     int slices = 1;
     PaPlan plan;  // one partial per block that touches a row tile
-    if (make_plan(plan, PA_ROWS, sink, m, q_len, G, Hkv)) slices = plan.max_seg;
+    if (get_plan(plan, sink, m, q_len, G, Hkv)) slices = plan.max_seg;
     return align256((size_t)slices * Hkv * score_stats_stride(G, q_len) * sizeof(float2));
 }
 

@@ -312,18 +312,53 @@ def gen_templates():
     print("g8 templates ok")
 
 
+def gen_e2e_d128(KVScore):
+    """G9: where north_star states mask parity - Qwen2.5-7B head geometry (H28 Hkv4 D128), 2 layers x 4 scoring chunks of 2000
+    tokens, ONE global threshold at ratio 0.3 over all 64 000 scores (attention/score.py:36-65 + :88-102).  Inputs are seeded
+    (tests/e2e_inputs.py) and regenerated on the GPU box; only scores, threshold, mask and an input checksum are stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_inputs as E
+    geom = E.GEOM
+    out = {}
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        K0, per_chunk = E.make(dt)
+        sc = KVScore()
+        sc.n_heads_kv, sc.dtype, sc.device, sc.n_layers = geom["Hkv"], dt, "cpu", geom["L"]
+        sc.sink = geom["sink"]
+        sc.init_score()
+        for ci, (st, en, q_len) in enumerate(E.chunks()):
+            sc.start_idx, sc.end_idx = st, en
+            for l in range(geom["L"]):
+                q, kr = per_chunk[ci][l]
+                kfull = torch.cat([K0[l], kr], dim=2)     # what update() returns during the scoring pass (kvcache.py:75-78)
+                sc._get_score(q, kfull, l)
+        score = torch.stack(sc.score, 0)                  # [L, 1, Hkv, N]
+        valid, thres = sc._threshold(sc.score, 0.3)
+        out[f"{tag}/score"] = bits(score)
+        out[f"{tag}/thres"] = np.array([thres], dtype=np.float64)
+        out[f"{tag}/valid"] = np.packbits(valid.numpy().reshape(-1))
+        out[f"{tag}/checksum"] = np.array([E.checksum(K0, per_chunk)], dtype=np.int64)
+        print("g9", tag, "thres", thres, "kept", int(valid.sum()), "of", valid.numel())
+    out["geom"] = np.array([geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g9_e2e_d128.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     install_shims()
     from attention.score import KVScore
     from attention.kvcache import EvictCache, RetainCache
+    if "--only-e2e" in sys.argv:
+        gen_e2e_d128(KVScore)
+        return
     gen_score(KVScore)
     gen_threshold(KVScore)
     gen_head_scores(KVScore)
     gen_cache_sequence(EvictCache, RetainCache)
     gen_attn()
     gen_templates()
+    gen_e2e_d128(KVScore)
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print(f"wrote {OUT}: {total / 1e6:.2f} MB")
 

@@ -1,0 +1,45 @@
+"""Seeded inputs of the multi-layer, multi-chunk D = 128 parity case (tests/golden/g9_e2e_d128.npz).
+
+Shared by oracle/gen_golden.py (which feeds them to the REFERENCE's KVScore._get_score in the build container and stores the
+resulting scores) and by the GPU parity test (which regenerates them on the GPU box from the same seeds): only the scores, the
+threshold and the mask travel as fixtures - the inputs are 60 MB per dtype.  The fixture carries a checksum of the inputs so
+that a generator mismatch fails loudly instead of comparing different problems.
+"""
+import torch
+
+GEOM = dict(L=2, H=28, Hkv=4, D=128, sink=32, N=8000, chunk=2000)   # Qwen2.5-7B head geometry, 2 layers x 4 scoring chunks
+
+
+def chunks(geom=GEOM):
+    """(start, end, q_len) per scoring chunk exactly as model/wrapper.py:197-221 cuts them (13 / 26 repeat-prompt tokens)."""
+    out = []
+    for c, st in enumerate(range(0, geom["N"], geom["chunk"])):
+        m = min(geom["chunk"], geom["N"] - st)
+        out.append((geom["sink"] + st, geom["sink"] + st + m, m + (13 if c == 0 else 26)))
+    return out
+
+
+def make(dtype, geom=GEOM, seed=4242):
+    """-> (K0[L] [1,Hkv,sink+N,D], per chunk per layer (q [1,H,q,D], k_rep [1,Hkv,q,D])) as CPU tensors of `dtype`."""
+    g = torch.Generator().manual_seed(seed)
+    L, H, Hkv, D = geom["L"], geom["H"], geom["Hkv"], geom["D"]
+    K0 = [torch.randn(1, Hkv, geom["sink"] + geom["N"], D, generator=g).to(dtype) for _ in range(L)]
+    per_chunk = []
+    for (st, en, q_len) in chunks(geom):
+        per_layer = []
+        for _ in range(L):
+            q = torch.randn(1, H, q_len, D, generator=g).to(dtype)
+            kr = torch.randn(1, Hkv, q_len, D, generator=g).to(dtype)
+            per_layer.append((q, kr))
+        per_chunk.append(per_layer)
+    return K0, per_chunk
+
+
+def checksum(K0, per_chunk) -> int:
+    """order-sensitive 63-bit checksum of the 16-bit patterns of every input tensor"""
+    acc = 0
+    for t in list(K0) + [x for pl in per_chunk for pair in pl for x in pair]:
+        v = t.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+        w = torch.arange(1, v.numel() + 1, dtype=torch.int64) % 1000003
+        acc = (acc * 1000003 + int((v.view(-1) * w).sum().item())) % (1 << 63)
+    return acc

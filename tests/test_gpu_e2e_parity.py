@@ -1,0 +1,75 @@
+"""GPU: eviction-mask parity where north_star states it - D = 128, several layers and chunks, ONE global threshold.
+
+Qwen2.5-7B head geometry (H28 Hkv4 D128), 2 layers x 4 scoring chunks of 2000 tokens (64 000 scores), ratio 0.3, fp16 and
+bf16.  The expected scores, threshold and mask were produced by the REFERENCE's own KVScore._get_score / _threshold
+(attention/score.py:36-65, :88-102) from the seeded inputs of tests/e2e_inputs.py (oracle/gen_golden.py:gen_e2e_d128) and are
+committed as tests/golden/g9_e2e_d128.npz.  Here the same inputs go through the drop-in cache object (update -> _get_score
+-> slice per chunk, then prune) and every number north_star names is printed and bounded at 2x its measured value
+(profiles/r3_parity_e2e.txt).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import e2e_inputs as E
+from conftest import from_bits, load_golden, ulp_diff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# measured on MI355X (profiles/r3_parity_e2e.txt); the assertions allow twice the measured deviation
+BOUNDS = {
+    # tag: (min bit-identical fraction, min within-one-half-ulp fraction, worst half-ulps, max Hamming fraction)
+    "f16": (0.9985, 0.9997, 6, 2e-4),
+    "bf16": (0.9996, 1.0, 2, 2e-4),
+}
+
+
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+def test_e2e_mask_parity_d128_multilayer(tag):
+    from kvzip_amd.kvcache import EvictCache
+    g = load_golden("g9_e2e_d128.npz")
+    geom = E.GEOM
+    assert [geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")] == g["geom"].tolist()
+    dt = torch.float16 if tag == "f16" else torch.bfloat16
+    K0, per_chunk = E.make(dt)
+    assert E.checksum(K0, per_chunk) == int(g[f"{tag}/checksum"][0]), "seeded inputs differ from the ones the fixture was made from"
+    L, H, Hkv, D, sink, N = (geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N"))
+    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dt, verbose=False)
+    for l in range(L):
+        kv.update(K0[l].to(DEV), K0[l].to(DEV), l)     # (values are irrelevant for the scores)
+    kv.init_score()
+    for ci, (st, en, q_len) in enumerate(E.chunks()):
+        kv.start_idx, kv.end_idx = st, en
+        seen = kv._seen_tokens
+        for l in range(L):
+            q, kr = per_chunk[ci][l]
+            k_all, _ = kv.update(kr.to(DEV), kr.to(DEV), l)
+            kv._get_score(q.to(DEV), k_all, l)
+        kv.slice(seen)
+    kv.start_idx, kv.get_score = sink, False
+    want = from_bits(g[f"{tag}/score"], tag == "bf16")                       # [L, 1, Hkv, N] from the reference
+    got = torch.stack([s for s in kv.score], 0).cpu()
+    d = ulp_diff(got, want)
+    exact, within1, worst = float((d == 0).float().mean()), float((d <= 1).float().mean()), int(d.max())
+    want_valid = torch.from_numpy(np.unpackbits(g[f"{tag}/valid"])[:want.numel()]).bool().view(want.shape)
+    want_thres = float(g[f"{tag}/thres"][0])
+    thres, r_real = kv.prune(0.3)
+    ham = int((kv.valid.cpu() != want_valid).sum())
+    print(f"\nE2E D=128 {tag}: {want.numel()} scores of {L} layers x {len(E.chunks())} chunks: {exact:.5f} bit-identical, {within1:.5f} within "
+          f"one half-ulp, worst {worst}; thres {thres!r} vs reference {want_thres!r} ({'EQUAL' if thres == want_thres else 'DIFFERENT'}); "
+          f"mask Hamming distance {ham} of {want.numel()}; kept ratio {r_real:.5f}")
+    lo_exact, lo_within1, hi_worst, hi_ham = BOUNDS[tag]
+    assert exact >= lo_exact and within1 >= lo_within1 and worst <= hi_worst
+    assert thres == want_thres, "the global threshold (one order statistic over all layers and chunks) must be the reference's"
+    assert ham <= hi_ham * want.numel()
+    # identical scores -> identical mask, bit for bit (the integer part of the contract)
+    kv2 = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dt, verbose=False)
+    for l in range(L):
+        kv2.update(K0[l].to(DEV), K0[l].to(DEV), l)
+    kv2.score = [want[l].to(DEV) for l in range(L)]
+    t2, _ = kv2.prune(0.3)
+    assert t2 == want_thres and torch.equal(kv2.valid.cpu(), want_valid)

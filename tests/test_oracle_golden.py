@@ -218,3 +218,28 @@ def test_varlen_attn_matches_torch_sdpa():
             want = F.scaled_dot_product_attention(qh.unsqueeze(0), kh.expand(1, G, -1, -1), vh.expand(1, G, -1, -1),
                                                   attn_mask=mask).squeeze(0).transpose(0, 1)   # [q_len, G, D]
             assert torch.allclose(got[h * q_len:(h + 1) * q_len], want, atol=2e-3, rtol=0)
+
+
+def test_oracle_pinned_on_e2e_d128_fixture_sample():
+    """G9 (Qwen2.5-7B head geometry, reference-generated): the oracle restatement reproduces the reference's scores of one
+    (layer, chunk) call bit for bit, and its threshold / mask on the reference's own scores (the whole fixture is checked on the
+    GPU box by tests/test_gpu_e2e_parity.py; one call keeps the CPU suite short)."""
+    import e2e_inputs as E
+    g = load_golden("g9_e2e_d128.npz")
+    geom = E.GEOM
+    K0, per_chunk = E.make(torch.float16)
+    assert E.checksum(K0, per_chunk) == int(g["f16/checksum"][0])
+    want = from_bits(g["f16/score"], False)
+    ci, l = 3, 1
+    st, en, q_len = E.chunks()[ci]
+    q, kr = per_chunk[ci][l]
+    # a quarter of the query heads' worth of work would change the result (max over ALL rows): run the call in full
+    got = orc.get_score(q, torch.cat([K0[l], kr], dim=2), geom["sink"], st, en)
+    assert torch.equal(to_bits_t(got), to_bits_t(want[l][:, :, st - geom["sink"]:en - geom["sink"]]))
+    valid, thres = orc.threshold([want[i] for i in range(geom["L"])], 0.3)
+    assert thres == float(g["f16/thres"][0])
+    assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g["f16/valid"])
+
+
+def to_bits_t(t):
+    return t.contiguous().view(torch.int16)
