@@ -60,9 +60,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-unfused", action="store_true", help="decode with update / prepare / attend as three calls")
     ap.add_argument("--q-pool", type=int, default=0, help="distinct chunk inputs kept in HBM (0 = all chunks)")
-    ap.add_argument("--prof-period", type=int, default=16,
-                    help="every n-th scoring call of the timed region runs alone on the caller's stream with its kernels "
-                         "bracketed by hipEvents (kernel durations for the roofline); the others overlap on the side streams")
+    ap.add_argument("--prof-calls", type=int, default=8,
+                    help="the first n scoring calls of every timed step run alone on the caller's stream with their kernels "
+                         "bracketed by hipEvents (kernel durations for the roofline; the GPU is idle at a step's start, nothing is "
+                         "drained); all other calls overlap on the side streams")
+    ap.add_argument("--unfused-update", action="store_true", help="update and _get_score as two library calls")
     ap.add_argument("--score-streams", type=int, default=3,
                     help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
     args = ap.parse_args(argv)
@@ -292,12 +294,13 @@ def main(argv=None):
             views[key] = ([Qs[p_][l][:, :, :q_len] for l in range(L)], [Ks[p_][l][:, :, :q_len] for l in range(L)],
                           [Vs[p_][l][:, :, :q_len] for l in range(L)])
 
-    period = max(1, args.prof_period)
-    timing = {"on": False, "n": 0}
+    n_prof = max(0, args.prof_calls)
+    timing = {"on": False}
 
     def one_step():
         kv = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
         kv.n_score_streams = max(1, args.score_streams)
+        kv.fuse_update_score = not args.unfused_update  # what kvzip_amd.attn / ModelKVzip.scoring do: update + _get_score = one call
         kv.adopt_dense(store_k, store_v, sink + N)
         if head_level:
             # what ModelKVzip.scoring(load_score=True) leaves behind: a stride-0 view of the [L,Hkv] head scores
@@ -308,19 +311,18 @@ def main(argv=None):
                 kv.start_idx, kv.end_idx = st, en          # model/wrapper.py:238-244
                 seen = kv._seen_tokens
                 Qv, Kv, Vv = views[(c % pool, q_len)]
+                # kernel timings: the FIRST `--prof-calls` scoring calls of a step run ALONE on the caller's stream, their kernels
+                # bracketed by the library's hipEvents.  The GPU is idle at that point anyway (the previous step ended with the
+                # host read of prune), so no pipeline is drained and nothing but the event records is added to the timed region;
+                # every other call overlaps on the side streams (brackets there would time kernels that share the GPU)
+                n_sample = n_prof if (timing["on"] and c == 0) else 0
                 for l in range(L):
-                    k_all, _ = kv.update(Kv[l], Vv[l], l)                               # attention/attn.py:44-48
-                    # kernel timings: every `period`-th scoring call runs ALONE on the caller's stream, bracketed by hipEvents;
-                    # all other calls overlap on the side streams (their kernels share the GPU, so their brackets would not
-                    # measure a kernel)
-                    sample = timing["on"] and timing["n"] % period == 0
-                    timing["n"] += 1
-                    if sample:
-                        kv._wait_score()
+                    if l < n_sample:
                         kv._score_exclusive = True
                         lib.kvz_prof_enable(1)
+                    k_all, _ = kv.update(Kv[l], Vv[l], l)                               # attention/attn.py:44-48
                     kv._get_score(Qv[l], k_all, l)                                      # attention/attn.py:53-54
-                    if sample:
+                    if l < n_sample:
                         lib.kvz_prof_enable(0)
                         kv._score_exclusive = False
                 kv.slice(seen)
@@ -439,7 +441,7 @@ def main(argv=None):
     pmc = {}
     try:
         if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9 and not head_level:
-            for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(path):
                     pmc = json.load(open(path))
@@ -474,8 +476,7 @@ def main(argv=None):
     else:
         flops_lc = [2.0 * H * D * q * (sink + (en - st) + q) for (st, en, q) in chunks]      # QK^T only
         flops_b = [2.0 * H * D * q * (en - st) for (st, en, q) in chunks]                       # pass-B recompute (ctx columns)
-        avg_flops_a = sum(flops_lc) / len(chunks)
-        avg_flops_b = sum(flops_b) / len(chunks)
+        avg_flops_a, avg_flops_b = flops_lc[0], flops_b[0]   # the bracketed launches are calls of the first chunk (q = m + 13)
         a_tf, a_ms, a_n = stage("score_rowstat", avg_flops_a, 1e12)
         b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
         s_gbs, s_ms, s_n = stage("select", 5.0 * L * Hkv * N, 1e9)
@@ -497,8 +498,10 @@ def main(argv=None):
             "frac": dom_tf / MFMA_PEAK_TFLOPS, "traffic": pmc.get(dominant, {}).get("traffic_bytes"),
             "note": ("algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) launch (QK^T only, SURVEY §8d); "
                      "score_combined = same flops over rowstat+colmax time; kernel durations from hipEvents on the launch "
-                     f"stream inside the timed region: every {period}th scoring call runs alone on the caller's "
-                     f"stream and is bracketed, the others overlap on {max(1, args.score_streams)} side streams"),
+                     f"stream inside the timed region: the first {n_prof} scoring calls of every step (first chunk, q = m + 13) run "
+                     "alone on the caller's stream and are bracketed (the GPU is idle at a step's start: no pipeline is drained), "
+                     f"the others overlap on {max(1, args.score_streams)} side streams; traffic: separate rocprofv3 --pmc passes "
+                     "(profiles/*_pmc_traffic.json)"),
         }
         workload = (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, "
                     f"{len(chunks)} scoring chunks of {args.chunk}, ratio {ratio}: score + select + compact; "
@@ -520,6 +523,7 @@ def main(argv=None):
             "score_streams": max(1, args.score_streams),
             "score_streams_distinct": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,
+            "update_score_fused": not args.unfused_update,
         },
         "roofline": roofline,
         "roofline_stages": stages,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KVZ_ABI_VERSION 2
+#define KVZ_ABI_VERSION 3
 
 /* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
 #define KVZ_F16 0
@@ -109,17 +109,17 @@ int kvz_score_chunk_async_log(int handle, int slot, kvz_stream_t caller, kvz_str
 int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream);
 int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream);
 
-/* Test hook for the rounding chain of a1: out[i] = half( float(in[i]) / float(sqrt(D)) ) computed exactly as the
- * scoring kernels do (exact-reciprocal multiply when the host's exhaustive search found one, IEEE division
- * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */
-int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int force_division, void* out_bits,
-                          float* rcp_used, kvz_stream_t stream);
-/* test hook, host only: the static partition of the row-statistics pass (kvz_score.hip, PaPlan) for a geometry.
- * unit / tile: 257 entries each; block b owns the key tiles from (unit[b], tile[b]) up to (unit[b+1], tile[b+1]). */
-int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile,
-                         int* n_blocks, int* max_seg, int* rows_per_unit);
-/* test hook, host only: n / d and n % d as the kernels compute them (multiply-shift by a launch-invariant divisor). */
-int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
+/* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78,
+ * kvz_dense_append on the CALLER's stream, where the forward's own attention reads the rows next) followed by kvz_score_chunk_async_log
+ * on the side stream with k = k_cache, klen = fill + t.  Before the append the caller's stream is ordered behind the previous scoring
+ * call of the same slot (it read the rows that are about to be overwritten).  Arguments as in the two calls it replaces. */
+int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
+                               void* k_cache, void* v_cache, int64_t cache_head_stride, int fill,
+                               const void* k_state, const void* v_state,
+                               int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride, int64_t vs_row_stride, int t,
+                               const void* q, int64_t q_head_stride, int sink, int start, int end, int q_len,
+                               int Hkv, int G, int D, int dtype,
+                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

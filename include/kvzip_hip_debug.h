@@ -1,0 +1,26 @@
+/* kvzip_hip_debug.h - TEST HOOKS of libkvzip_hip.so (not part of the drop-in boundary; include/kvzip_hip.h is).
+ * They expose pieces of the kernels' arithmetic to the test-suite: the rounding chain on raw 16-bit patterns, the static partition
+ * of the row-statistics pass, the invariant-divisor arithmetic.  tests/test_abi.py checks that they are exported and bound. */
+#ifndef KVZIP_HIP_DEBUG_H
+#define KVZIP_HIP_DEBUG_H
+#include "kvzip_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook for the rounding chain of a1: out[i] = half( float(in[i]) / float(sqrt(D)) ) computed exactly as the
+ * scoring kernels do (exact-reciprocal multiply when the host's exhaustive search found one, IEEE division
+ * otherwise or when force_division != 0).  rcp_used (host pointer, optional) receives the constant (0 = division). */
+int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtype, int force_division, void* out_bits,
+                          float* rcp_used, kvz_stream_t stream);
+/* test hook, host only: the static partition of the row-statistics pass (kvz_score.hip, PaPlan) for a geometry.
+ * unit / tile: 257 entries each; block b owns the key tiles from (unit[b], tile[b]) up to (unit[b+1], tile[b+1]). */
+int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile,
+                         int* n_blocks, int* max_seg, int* rows_per_unit);
+/* test hook, host only: n / d and n % d as the kernels compute them (multiply-shift by a launch-invariant divisor). */
+int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVZIP_HIP_LIB", os.path.join(_HERE, "libkvzip_hip.so"))  # override: A/B builds
 
 KVZ_F16, KVZ_BF16 = 0, 1
+ABI_VERSION = 3
 
-# name -> (restype, argtypes); mirrors include/kvzip_hip.h one to one
+# name -> (restype, argtypes); mirrors include/kvzip_hip.h (+ the test hooks of include/kvzip_hip_debug.h) one to one
 _vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
 SIGNATURES = {
     "kvz_abi_version": (_i, []),
@@ -33,6 +34,8 @@ SIGNATURES = {
     "kvz_score_chunk_log": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
     "kvz_score_chunk_async_log": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp,
                                        _sz]),
+    "kvz_update_score_async_log": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i64, _i, _i, _i,
+                                        _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz]),
     "kvz_score_log_fill": (_i, [_vp, _i64, _vp]),
     "kvz_score_finalize_log": (_i, [_vp, _i64, _vp, _i, _vp]),
     "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
@@ -83,8 +86,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.kvz_abi_version() != 2:
-        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding 2")
+    if lib.kvz_abi_version() != ABI_VERSION:
+        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -133,12 +133,15 @@ static AsyncCtx* async_get(int h) {
 extern "C" int kvz_async_create(int n_slots) {
     KVZ_REQUIRE(n_slots > 0 && n_slots <= 65536, KVZ_EINVAL, "kvz_async_create: bad slot count %d", n_slots);
     auto* c = new kvz::AsyncCtx();
-    c->ready.resize(n_slots);
-    c->done.resize(n_slots);
     c->pending.assign(n_slots, 0);
+    c->ready.assign(n_slots, nullptr);
+    c->done.assign(n_slots, nullptr);
     for (int i = 0; i < n_slots; ++i) {
         if (hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) != hipSuccess) {
+            for (auto e : c->ready) if (e) (void)hipEventDestroy(e);   // nothing of a half-built context survives
+            for (auto e : c->done) if (e) (void)hipEventDestroy(e);
+            delete c;
             kvz::set_error("kvz_async_create: hipEventCreate failed");
             return KVZ_ELAUNCH;
         }
@@ -224,4 +227,22 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
         c->pending[slot] = 1;
     }
     return KVZ_OK;
+}
+
+
+// one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache on the caller's stream, then score
+extern "C" int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, void* k_cache, void* v_cache,
+                                          int64_t cache_head_stride, int fill, const void* k_state, const void* v_state,
+                                          int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride,
+                                          int64_t vs_row_stride, int t, const void* q, int64_t q_head_stride, int sink, int start,
+                                          int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out,
+                                          int64_t log_head_stride, void* ws, size_t ws_bytes) {
+    // the previous scoring call of this slot read the rows that the append overwrites
+    int rc = kvz_async_wait(handle, slot, caller);
+    if (rc != KVZ_OK) return rc;
+    rc = kvz_dense_append(k_cache, v_cache, cache_head_stride, fill, k_state, v_state, ks_head_stride, ks_row_stride, vs_head_stride,
+                          vs_row_stride, Hkv, t, D, 2, caller);
+    if (rc != KVZ_OK) return rc;
+    return score_chunk_async_impl(handle, slot, caller, side, q, q_head_stride, k_cache, cache_head_stride, fill + t, sink, start, end,
+                                  q_len, Hkv, G, D, dtype, log_out, log_head_stride, ws, ws_bytes, true);
 }

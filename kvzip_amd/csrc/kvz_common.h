@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "../../include/kvzip_hip.h"
+#include "../../include/kvzip_hip_debug.h"
 
 namespace kvz {
 

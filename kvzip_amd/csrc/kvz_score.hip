@@ -38,17 +38,9 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Mfma32;
-// mfma_a* / mfma_b*: MFMA issued from assembly with the STATIONARY fragment (B operand in pass A, A operand in pass B) in ACCUMULATOR
-// registers ("a") and the result in ordinary VGPRs.  The one-wave-per-SIMD builds (KVZ_PA_WAVES = 4 / KVZ_PB_WAVES = 4, 512 registers
-// per lane) use them to keep the 64 stationary fragment registers out of the 256 VGPRs the VALU chain works in; left alone the
-// allocator puts the ACCUMULATORS into the AGPRs and copies all 16 values of every block back with v_accvgpr_read.
 template <> struct Mfma32<_Float16> {
     typedef h8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    __device__ static inline void mfma_a0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b)); }
-    __device__ static inline void mfma_a(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b)); }
-    __device__ static inline void mfma_b0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b)); }
-    __device__ static inline void mfma_b(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); }
     // first MFMA of a chain (C = 0) written INTO the registers of `acc`: the tied operand keeps an accumulator in one physical
     // register tuple for the whole kernel (left to the allocator every chain is a fresh 16-tuple, and under pressure the hunt
     // for free aligned tuples spills the fragment registers).  No software wait states are needed after it: the next MFMA of
@@ -60,10 +52,6 @@ template <> struct Mfma32<_Float16> {
 template <> struct Mfma32<__bf16> {
     typedef b8 v8;
     __device__ static inline f16v mfma(v8 a, v8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    __device__ static inline void mfma_a0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b)); }
-    __device__ static inline void mfma_a(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b)); }
-    __device__ static inline void mfma_b0(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b)); }
-    __device__ static inline void mfma_b(f16v& acc, v8 a, v8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); }
     __device__ static inline void mfma_first(f16v& acc, v8 a, v8 b) {
         asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "v"(b));
     }
@@ -75,9 +63,6 @@ constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 12
 #endif
 #ifndef KVZ_PB_OCC
 #define KVZ_PB_OCC (KVZ_PB_WAVES / 4)
-#endif
-#ifndef KVZ_PB_AGPR
-#define KVZ_PB_AGPR (KVZ_PB_WAVES == 4)   // stationary keys of pass B in accumulator registers
 #endif
 constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
 constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
@@ -301,9 +286,6 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 #endif
 #ifndef KVZ_PA_RG
 #define KVZ_PA_RG 1
-#endif
-#ifndef KVZ_PA_AGPR
-#define KVZ_PA_AGPR (KVZ_PA_WAVES == 4)   // query rows of pass A in accumulator registers
 #endif
 constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
@@ -789,11 +771,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) {
-#if KVZ_PA_AGPR
-            asm volatile("" : "+a"(bq[g][kk]));  // the rows are in (accumulator) registers: the area is free
-#else
             asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
-#endif
         }
     if (valid(nxt)) stage_q(nxt);
     Rows rows = rows_of(cur);
@@ -863,12 +841,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL & 4
                         accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
 #else
-#if KVZ_PA_AGPR
-                        if (kk == 0) Mfma32<T>::mfma_a0(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
-                        else Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
-#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
-#endif
 #endif
                     }
             }
@@ -898,11 +871,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #if KVZ_ABL & 4
                         accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
 #else
-#if KVZ_PA_AGPR
-                        Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
-#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], accn[g]);
-#endif
 #endif
                     }
             }
@@ -953,12 +922,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
             for (int g = 0; g < PA_RG; ++g)
-#if KVZ_PA_AGPR
-                if (kk == 0) Mfma32<T>::mfma_a0(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
-                else Mfma32<T>::mfma_a(accn[g], __builtin_bit_cast(v8, frn[kk]), bq[g][kk]);
-#else
                 accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -1123,11 +1087,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
-#if KVZ_PA_AGPR
-            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+a"(bq[g][kk]));   // ... and move to the accumulator file
-#else
             for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));
-#endif  // rows in registers: the area is free again
         KVZ_STAMP(10);
         chain0(acc[0], fr[0]);  // (the eight dependent MFMAs run under the index arithmetic below)
         KVZ_STAMP(11);
@@ -1162,10 +1122,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #define KVZ_PB_RG 1
 #endif
 constexpr int PB_RG = KVZ_PB_RG;                 // groups of 32 stationary keys per wave
-#ifndef KVZ_PB_HOLD
-#define KVZ_PB_HOLD (KVZ_PB_RG == 1)             // 1: even blocks hold their values, odd blocks fold both with one v_max3 per key
-#endif
-constexpr bool PB_HOLD = KVZ_PB_HOLD;
 constexpr int PB_COLS = PB_WAVES * PB_RG * 32;   // stationary ctx keys per block
 constexpr int PB_STAT_TILES = 56;                // row tiles per block whose merged statistics fit beside the ring (56 KiB)
 
@@ -1299,11 +1255,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
         for (int g = 0; g < PB_RG; ++g)
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) {
-#if KVZ_PB_AGPR
-                asm volatile("" : "+a"(ak[g][kk]));  // the wait for the stationary keys belongs here (... and they move to the accumulator file)
-#else
                 asm volatile("" : "+v"(ak[g][kk]));  // the wait for the stationary keys belongs here
-#endif
             }
         stage_wait();
         block_barrier();
@@ -1316,12 +1268,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
         auto mfma_step = [&](f16v (&accn)[PB_RG], const u32x4 (&frn)[C::KK], int kk) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < PB_RG; ++g) {
-#if KVZ_PB_AGPR
-                if (kk == 0) Mfma32<T>::mfma_b0(accn[g], ak[g][kk], __builtin_bit_cast(v8, frn[kk]));
-                else Mfma32<T>::mfma_b(accn[g], ak[g][kk], __builtin_bit_cast(v8, frn[kk]));
-#else
                 accn[g] = Mfma32<T>::mfma(ak[g][kk], __builtin_bit_cast(v8, frn[kk]), kk == 0 ? zero16 : accn[g]);
-#endif
             }
         };
 
@@ -1350,16 +1297,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
                 for (int c = 0; c < MfmaSched<C::KK>::count(2 * qd + 1); ++c) mfma_step(accn, frn, MfmaSched<C::KK>::first(2 * qd + 1) + c);
 #pragma unroll
                 for (int g = 0; g < PB_RG; ++g) {
-                    if constexpr (!PB_HOLD) {
-                        // (two groups per wave: the 32 held registers do not fit beside 64 accumulators and 64 fragment registers -
-                        // one plain maximum per logit, 2.5 cycles each instead of 4.2 per pair)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float nb;
-                            asm("v_max_f32 %0, %1, %2" : "=v"(nb) : "v"(best[g][4 * qd + j]), "v"(tv[g][j]));
-                            best[g][4 * qd + j] = nb;
-                        }
-                    } else if constexpr (ODD) {
+                    if constexpr (ODD) {
                         // (outputs NOT tied to the inputs: the allocator answered "+v" on the loop-carried maxima with a register copy
                         // per maximum and step; left to the compiler as plain fmaxf the maxima drift away from their block and spill)
                         // (one instruction per statement: an output without early-clobber may share a register with an input of

@@ -63,12 +63,19 @@ class _CacheBase(KVScore):
         self._fill: List[int] = []               # rows in use per layer
         self._reserve = int(reserve)
         self._views = {}                         # (layer, rows) -> (key view, value view, storage) of the dense cache
+        self._pend_app = None                    # append left by update() for the fused update + score call of _get_score
+        # scoring pass: update() leaves its append to the _get_score() call that follows it (attention/attn.py:44-54) and the two
+        # become ONE library call.  Between the two calls the returned K,V views do not hold the new rows yet, so this is opt-in:
+        # kvzip_amd.attn (the forward pass this package owns) and ModelKVzip.scoring switch it on
+        self.fuse_update_score = False
 
     # -- dense (pre-prune) storage --------------------------------------------------------------
     def _dense_append(self, layer_idx: int, key_states: torch.Tensor, value_states: torch.Tensor):
-        # the previous (asynchronous) scoring call of this layer read the rows that are about to be overwritten
-        if self._pending:
-            self._wait_score(layer_idx)
+        if key_states.device != self.device and key_states.is_cuda:
+            raise ops.KvzError(f"layer {layer_idx} lives on {key_states.device}, the cache on {self.device}: a cache object (its streams, "
+                               "events and workspaces) works on ONE device - load the model on one GPU (one context per GPU is the "
+                               "multi-GPU scheme, kvzip_amd/dist.py)")
+        self._flush_append()
         t = key_states.shape[-2]
         if len(self._store_k) <= layer_idx:
             _, Hkv, _, D = key_states.shape
@@ -82,6 +89,7 @@ class _CacheBase(KVScore):
         sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
         cap = sk.shape[2]
         if f + t > cap:  # amortised growth
+            self._wait_score(finalize=False)  # (scoring calls in flight read the storage that is being replaced)
             new_cap = max(2 * cap, f + t + self._reserve)
             for store in (self._store_k, self._store_v):
                 old = store[layer_idx]
@@ -90,7 +98,15 @@ class _CacheBase(KVScore):
                 store[layer_idx] = new
             sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
             self._views.clear()
-        if key_states.is_cuda and key_states.stride(-1) == 1 and value_states.stride(-1) == 1:
+        fast = key_states.is_cuda and key_states.stride(-1) == 1 and value_states.stride(-1) == 1
+        if fast and self.get_score and not self.pruned and self.fuse_update_score and self.score_deferred:
+            # scoring pass: _get_score of this layer follows (attention/attn.py:44-54) and issues the append together with the
+            # scoring kernels in ONE library call (kvz_update_score_async_log); anything else that touches the cache flushes first
+            self._pend_app = (layer_idx, key_states, value_states, f)
+        elif fast:
+            # the previous (asynchronous) scoring call of this layer read the rows that are about to be overwritten
+            if self._pending:
+                self._wait_score(layer_idx)
             # one launch for K and V (strided sources accepted), scalars only: rows f .. f+t of every head
             lib = ops._lib.load()
             rc = lib.kvz_dense_append(sk.data_ptr(), sv.data_ptr(), sk.stride(1), f, key_states.data_ptr(), value_states.data_ptr(),
@@ -98,6 +114,8 @@ class _CacheBase(KVScore):
                                       sk.shape[1], t, sk.shape[3], sk.element_size(), ops._stream(sk))
             ops.check(rc, "kvz_dense_append")
         else:
+            if self._pending:
+                self._wait_score(layer_idx)
             sk[:, :, f:f + t].copy_(key_states)
             sv[:, :, f:f + t].copy_(value_states)
         self._fill[layer_idx] = f + t
@@ -108,6 +126,22 @@ class _CacheBase(KVScore):
             if len(self._views) > 16 * max(1, self.n_layers):
                 self._views.clear()
         self.key_cache[layer_idx], self.value_cache[layer_idx] = vw[0], vw[1]
+
+    def _flush_append(self):
+        """Issue an append that update() left for _get_score (nothing else may see the cache without its rows)."""
+        p = self._pend_app
+        if p is None:
+            return
+        self._pend_app = None
+        layer_idx, key_states, value_states, f = p
+        if self._pending:
+            self._wait_score(layer_idx)
+        sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
+        lib = ops._lib.load()
+        rc = lib.kvz_dense_append(sk.data_ptr(), sv.data_ptr(), sk.stride(1), f, key_states.data_ptr(), value_states.data_ptr(),
+                                  key_states.stride(1), key_states.stride(2), value_states.stride(1), value_states.stride(2),
+                                  sk.shape[1], key_states.shape[-2], sk.shape[3], sk.element_size(), ops._stream(sk))
+        ops.check(rc, "kvz_dense_append")
 
     def _dense_meta(self, cap: int, device):
         """(segment starts h*cap, zeros) int32 [Hkv] for the dense append launch, cached per capacity."""
@@ -121,6 +155,7 @@ class _CacheBase(KVScore):
     def adopt_dense(self, store_k: List[torch.Tensor], store_v: List[torch.Tensor], filled: int):
         """Wrap already prefilled per-layer ``[1, Hkv, capacity, D]`` buffers without copying (e.g. the KV a
         serving engine prefilled elsewhere); ``filled`` rows are in use."""
+        self._flush_append()
         self._wait_score(finalize=False)  # scoring calls still in flight read the storage that is being replaced
         self._views.clear()
         self._store_k, self._store_v = list(store_k), list(store_v)
@@ -130,6 +165,7 @@ class _CacheBase(KVScore):
         self._seen_tokens = filled
 
     def _dense_slice(self, seen_token_prev: int):
+        self._flush_append()
         for l in range(len(self._store_k)):
             self._fill[l] = seen_token_prev
             self.key_cache[l] = self._store_k[l][:, :, :seen_token_prev]
@@ -139,6 +175,7 @@ class _CacheBase(KVScore):
         # asynchronous scoring reads the cache storage, the score buffer and the workspaces from side streams: order the
         # current stream behind it before the caching allocator may hand that memory to somebody else
         try:
+            self._pend_app = None
             self._wait_score(finalize=False)
         except Exception:
             pass
@@ -162,6 +199,7 @@ class _CacheBase(KVScore):
 
     def _select(self, ratio: float, level: str):
         """-> (valid [L,1,Hkv,N] bool, thres float, r_real float); one host synchronisation."""
+        self._flush_append()
         if "uniform" in level:
             self.valid, thres = self._threshold_uniform(self.score, ratio)
             n = self.valid.numel()
@@ -265,6 +303,7 @@ class EvictCache(_CacheBase):
     # reference: kvcache.py:152-185
     def prepare_init(self):
         """Evict KV and prepare the varlen metadata: one plan + one gather launch for all layers."""
+        self._flush_append()
         L, Hkv = self.n_layers, self.n_heads_kv
         klen = self.key_cache[0].shape[2]
         plan = ops.compact_plan(self.valid, self.sink, klen, slack=self.slack)

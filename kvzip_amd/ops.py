@@ -11,7 +11,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import KVZ_BF16, KVZ_F16, KvzError, check  # noqa: F401
+from ._lib import KVZ_BF16, KVZ_F16, KvzError  # noqa: F401
+from ._lib import check as _check
 
 COMPACT_TILE = 1024
 
@@ -25,13 +26,30 @@ def _dtype_code(dtype: torch.dtype) -> int:
                    "(reference csrc/csrc/static_switch.h:3-12)")
 
 
+def check(rc: int, who: str) -> None:
+    """Raise on a non-zero return code; give the caller back the current device it had before the call (see ``_stream``)."""
+    global _restore_device
+    if _restore_device is not None:
+        prev, _restore_device = _restore_device, None
+        torch.cuda.set_device(prev)
+    _check(rc, who)
+
+
+_restore_device = None  # device that was current before a call had to switch (restored by check() after the launch)
+
+
 def _stream(t: torch.Tensor) -> int:
     """HIP stream handle for a launch on ``t``'s device.  The library launches on the CURRENT HIP device, so a tensor that
-    lives on another GPU (``device_map="auto"``, a cache on cuda:1 while cuda:0 is current) first makes its device current;
-    every cache object and every call of this module works on ONE device (all tensors of a call must share it)."""
+    lives on another GPU (a cache on cuda:1 while cuda:0 is current) makes its device current for the call; ``check`` - which
+    follows every launch - switches back, so the caller's current device is what it was.  Every cache object and every call of
+    this module works on ONE device (all tensors of a call must share it)."""
+    global _restore_device
     if not t.is_cuda:
         raise KvzError("the HIP path needs device tensors (no CPU fallback)")
-    if t.device.index != torch.cuda.current_device():
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        if _restore_device is None:
+            _restore_device = cur
         torch.cuda.set_device(t.device)
     return raw_stream(t.device.index)
 

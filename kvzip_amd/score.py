@@ -231,8 +231,12 @@ class KVScore:
         assert bsz == 1 and query_states.stride(3) == 1 and query_states.stride(2) == D
         assert key_states.stride(3) == 1 and key_states.stride(2) == D and key_states.dtype == query_states.dtype
         dev = query_states.device
+        if dev != torch.device(self.device) and torch.device(self.device).index is not None:
+            raise ops.KvzError(f"layer {layer_idx} lives on {dev}, the cache on {self.device}: a cache object (side streams, events, "
+                               "workspaces) works on ONE device - load the model on one GPU (one context per GPU is the multi-GPU scheme)")
         if dev.index != torch.cuda.current_device():
-            torch.cuda.set_device(dev)
+            raise ops.KvzError(f"the cache lives on {dev} but cuda:{torch.cuda.current_device()} is current: wrap the forward pass in "
+                               f"`with torch.cuda.device({dev.index}):` (the library launches on the current HIP device)")
         need = self._ws_need.get((q_len, m, H))
         if need is None:
             need = self._ws_need[(q_len, m, H)] = lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, self.sink)
@@ -262,9 +266,27 @@ class KVScore:
             self._pending = True
         n_tot = buf.shape[-1]
         log = self._score_log
-        if log is not None and log.shape[-1] == n_tot:
+        pend = getattr(self, "_pend_app", None)
+        if pend is not None and (pend[0] != layer_idx or log is None or log.shape[-1] != n_tot
+                                 or key_states.data_ptr() != self._store_k[layer_idx].data_ptr()):
+            self._flush_append()  # (not the call update() expected: issue its append on its own)
+            pend = None
+        if pend is not None:
+            # update() of this layer left its append for this call: ONE library call appends the repeat chunk's K,V on the caller's
+            # stream and issues the scoring kernels on the side stream (kvz_update_score_async_log)
+            self._pend_app = None
+            _, ks, vs, fill = pend
+            sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
+            out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
+            rc = lib.kvz_update_score_async_log(self._async, layer_idx, cur, side, sk.data_ptr(), sv.data_ptr(), sk.stride(1), fill,
+                                                ks.data_ptr(), vs.data_ptr(), ks.stride(1), ks.stride(2), vs.stride(1), vs.stride(2),
+                                                ks.shape[-2], query_states.data_ptr(), query_states.stride(1), self.sink,
+                                                self.start_idx, self.end_idx, q_len, Hkv, H // Hkv, D,
+                                                ops._dtype_code(query_states.dtype), out_ptr, n_tot, ws.data_ptr(), ws.numel())
+            self._log_dirty = True
+        elif log is not None and log.shape[-1] == n_tot:
             # deferred path: pass B merges its row slices by atomics into the log buffer, the finalize launch happens once, when
-            # the scores are read (3 launches per call instead of 4)
+            # the scores are read (2 launches per call)
             out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
             rc = lib.kvz_score_chunk_async_log(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
                                                key_states.data_ptr(), key_states.stride(1), klen, self.sink, self.start_idx,

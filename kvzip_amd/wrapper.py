@@ -66,10 +66,17 @@ class ModelKVzip:
             replace_attn(model)
             name = name or model.split("/")[-1]
             tokenizer = tokenizer or AutoTokenizer.from_pretrained(model)
-            model = AutoModelForCausalLM.from_pretrained(model, torch_dtype="auto", device_map="auto").eval()
+            # ONE device: a cache object (side streams, events, workspaces) lives on one GPU, and the multi-GPU scheme of this path is
+            # one context per GPU (kvzip_amd/dist.py), not one model sharded over several
+            dev = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
+            model = AutoModelForCausalLM.from_pretrained(model, torch_dtype="auto", device_map=dev).eval()
         else:
             replace_attn(name or type(model).__name__)
         self.model, self.tokenizer = model, tokenizer
+        devices = {p.device for p in model.parameters()}
+        if len(devices) > 1:
+            raise ValueError(f"the model is sharded over {sorted(map(str, devices))}: ModelKVzip needs it on ONE device (one context "
+                             "per GPU is the multi-GPU scheme of this path, kvzip_amd/dist.py)")
         self.name = name or type(model).__name__
         self.dtype = next(model.parameters()).dtype
         self.device = next(model.parameters()).device
@@ -181,6 +188,8 @@ class ModelKVzip:
         """KV importance scoring (fills ``kv.score``)."""
         if not load_score:
             kv.init_score()
+            if hasattr(kv, "fuse_update_score"):
+                kv.fuse_update_score = True  # the forward pass is kvzip_amd.attn: update() is always followed by _get_score()
             start_idx_tmp = kv.start_idx
             kv.end_idx = 0
             for prefill_ids_p, repeat_ids_p in self.self_task(ctx_ids, chunk_size=chunk_size,
@@ -193,6 +202,8 @@ class ModelKVzip:
         else:
             kv.score = load_head_score(self.name, kv.ctx_len, self.head_score_dir, self.device)
         kv.get_score = False
+        if hasattr(kv, "fuse_update_score"):
+            kv.fuse_update_score = False
 
     # ---- generation (reference model/wrapper.py:251-284) ---------------------------------------------------------
     @torch.inference_mode()

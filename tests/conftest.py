@@ -46,3 +46,43 @@ def ulp_diff(a, b):
         x = t.detach().cpu().contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
         return torch.where(x >= 0x8000, 0x8000 - (x - 0x8000) - 1, x + 0x8000)
     return (key(a) - key(b)).abs()
+
+
+# ---- score parity bookkeeping -------------------------------------------------------------------------------------------
+# The scoring kernels follow the reference's rounding chain; what differs from the CPU oracle is the accumulation order of the
+# fp32 dot products (and exp / log implementations), so a small fraction of the 16-bit scores lands one or a few steps of the
+# 16-bit grid away.  Every GPU test that compares scores goes through check_score_parity: it prints the measured distribution,
+# records it (KVZ_RECORD_PARITY=1 -> gpurun_out/score_parity_measured.json) and bounds it at TWICE the values measured on MI355X
+# and committed in tests/golden/score_parity_measured.json (+2 elements of slack for the tiny cases); a case without a record
+# falls back to the structural bound (>= 97 % identical, >= 99.5 % within one step, worst 16 = one ulp of the winning logit).
+_MEASURED = None
+
+
+def _measured():
+    global _MEASURED
+    if _MEASURED is None:
+        import json
+        path = os.path.join(GOLDEN, "score_parity_measured.json")
+        _MEASURED = json.load(open(path)) if os.path.exists(path) else {}
+    return _MEASURED
+
+
+def check_score_parity(case: str, got, want):
+    import json
+    d = ulp_diff(got, want)
+    n = d.numel()
+    n_diff, n_far, worst = int((d != 0).sum()), int((d > 1).sum()), int(d.max()) if n else 0
+    print(f"\nPARITY {case}: {n} scores, {1 - n_diff / max(n, 1):.5f} bit-identical, {1 - n_far / max(n, 1):.5f} within one step, worst {worst}")
+    if os.environ.get("KVZ_RECORD_PARITY"):
+        path = os.path.join(ROOT, "gpurun_out", "score_parity_measured.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[case] = {"n": n, "not_identical": n_diff, "beyond_one_step": n_far, "worst": worst}
+        json.dump(rec, open(path, "w"), indent=0, sort_keys=True)
+    m = _measured().get(case)
+    if m is None:
+        assert n_diff <= 0.03 * n + 2 and n_far <= 0.005 * n + 1 and worst <= 16, (case, n, n_diff, n_far, worst)
+    else:
+        assert n_diff <= 2 * m["not_identical"] + 2 and n_far <= 2 * m["beyond_one_step"] + 1 and worst <= max(2 * m["worst"], 2), \
+            (case, n, n_diff, n_far, worst, m)
+    return 1 - n_diff / max(n, 1), 1 - n_far / max(n, 1), worst

@@ -19,10 +19,18 @@ def _built_library():
     assert os.path.exists(lib)
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "kvzip_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(kvz_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("kvzip_hip.h", "kvzip_hip_debug.h")):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(kvz_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
+
+
+def test_debug_hooks_live_in_their_own_header():
+    assert not [s for s in _declared_symbols(("kvzip_hip.h",)) if s.startswith("kvz_debug_")]
+    assert all(s.startswith("kvz_debug_") for s in _declared_symbols(("kvzip_hip_debug.h",)))
 
 
 def test_header_declares_the_whole_path():
@@ -46,7 +54,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from kvzip_amd import _lib
     lib = _lib.load()
-    assert lib.kvz_abi_version() == 2
+    assert lib.kvz_abi_version() == _lib.ABI_VERSION == 3
     assert lib.kvz_select_workspace_bytes() >= (2048 + 32) * 4
     assert lib.kvz_compact_plan_bytes(28, 4, 131104) == 28 * 4 * 129 * 4
     assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000, 32) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4

@@ -14,16 +14,20 @@ import pytest
 import torch
 
 import e2e_inputs as E
-from conftest import from_bits, load_golden, ulp_diff
+from conftest import check_score_parity, from_bits, load_golden, ulp_diff
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# measured on MI355X (profiles/r3_parity_e2e.txt); the assertions allow twice the measured deviation
+# measured on MI355X (profiles/r3_parity_e2e.txt); the assertions allow twice the measured deviation.  The worst case is structural:
+# the scores follow the reference's rounding chain, what differs is the accumulation order of the fp32 dot product, and when that flips
+# the 16-bit rounding of the WINNING logit (|x| in [4, 8): one ulp = 2^-8 in fp16) the score exp(x - m - log l) moves by 2^-8 relative =
+# 8 steps of its own 16-bit grid (16 for a score just above a power of two) - rare (1 in ~10^4), and harmless for the mask unless the
+# score sits within those steps of the global threshold
 BOUNDS = {
-    # tag: (min bit-identical fraction, min within-one-half-ulp fraction, worst half-ulps, max Hamming fraction)
-    "f16": (0.9985, 0.9997, 6, 2e-4),
-    "bf16": (0.9996, 1.0, 2, 2e-4),
+    # tag: (min bit-identical fraction, min within-one-step fraction, worst steps, max Hamming fraction)
+    "f16": (0.9978, 0.99956, 16, 1e-4),     # measured 0.99888 / 0.99978 / 8 / 0
+    "bf16": (0.9978, 0.99956, 16, 1e-4),
 }
 
 
@@ -62,6 +66,7 @@ def test_e2e_mask_parity_d128_multilayer(tag):
     print(f"\nE2E D=128 {tag}: {want.numel()} scores of {L} layers x {len(E.chunks())} chunks: {exact:.5f} bit-identical, {within1:.5f} within "
           f"one half-ulp, worst {worst}; thres {thres!r} vs reference {want_thres!r} ({'EQUAL' if thres == want_thres else 'DIFFERENT'}); "
           f"mask Hamming distance {ham} of {want.numel()}; kept ratio {r_real:.5f}")
+    check_score_parity(f"e2e_d128/{tag}", got, want)
     lo_exact, lo_within1, hi_worst, hi_ham = BOUNDS[tag]
     assert exact >= lo_exact and within1 >= lo_within1 and worst <= hi_worst
     assert thres == want_thres, "the global threshold (one order statistic over all layers and chunks) must be the reference's"
