@@ -316,6 +316,7 @@ def main(argv=None):
                 # host read of prune), so no pipeline is drained and nothing but the event records is added to the timed region;
                 # every other call overlaps on the side streams (brackets there would time kernels that share the GPU)
                 n_sample = n_prof if (timing["on"] and c == 0) else 0
+                t_c = time.perf_counter()
                 for l in range(L):
                     if l < n_sample:
                         kv._score_exclusive = True
@@ -325,6 +326,11 @@ def main(argv=None):
                     if l < n_sample:
                         lib.kvz_prof_enable(0)
                         kv._score_exclusive = False
+                if timing["on"] and c == 1:
+                    # pure host cost of an (update, _get_score) pair: the second chunk of a step is enqueued while the launch queues
+                    # are still shallow (84 kernels in flight), so the host is not yet throttled by the GPU
+                    timing["pair_s"] = timing.get("pair_s", 0.0) + (time.perf_counter() - t_c)
+                    timing["pairs"] = timing.get("pairs", 0) + L
                 kv.slice(seen)
         kv.start_idx, kv.get_score = sink, False
         timing["issued"] = time.perf_counter()
@@ -356,7 +362,6 @@ def main(argv=None):
 
     # ---- post-prune decode: append + variable-length attention, q_len = 1 (attention only) ------------------
     lib.kvz_prof_reset()
-    lib.kvz_prof_enable(1)
     T = args.decode_tokens
     qd = randn(L, 1, H, 1, D)
     kd, vd = randn(L, 1, Hkv, 1, D), randn(L, 1, Hkv, 1, D)
@@ -373,12 +378,30 @@ def main(argv=None):
     seen = kv._seen_tokens
     decode_tokens(2)
     torch.cuda.synchronize()
-    lib.kvz_prof_reset()
     t0 = time.perf_counter()
     decode_tokens(T)
     torch.cuda.synchronize()
     t_dec = time.perf_counter() - t0
+    # kernel durations: a few more tokens with the library's hipEvent brackets (kept out of the timed loop: two event records per
+    # launch are host work)
+    lib.kvz_prof_reset()
+    lib.kvz_prof_enable(1)
+    decode_tokens(min(T, 4))
+    torch.cuda.synchronize()
     lib.kvz_prof_enable(0)
+    # the same step as ONE HIP graph (EvictCache.decode_graph: static input buffers, device-side token counter): what a serving
+    # engine replays per token; the per-layer loop above is what a Python forward pass does
+    t_graph = None
+    if T > 0 and not args.decode_unfused:
+        step_graph = kv.decode_graph(qd, kd, vd)
+        for _ in range(2):
+            step_graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(T):
+            step_graph.replay()
+        torch.cuda.synchronize()
+        t_graph = time.perf_counter() - t0
     attn_ms, attn_n = prof_read(lib, "varlen_attn")
     kept_rows = sum(kv.info["rows_used"])
     len_k_host = kv.info["len_k_host"]
@@ -522,13 +545,18 @@ def main(argv=None):
             "gathered_contexts": len(records),
             "score_streams": max(1, args.score_streams),
             "score_streams_distinct": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
-            "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,
+            "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
+            "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,
             "update_score_fused": not args.unfused_update,
         },
         "roofline": roofline,
         "roofline_stages": stages,
-        "decode": {"tokens_per_s": T / t_dec, "ms_per_token": t_dec / T * 1e3, "tokens": T,
-                   "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded"},
+        "decode": {"tokens_per_s": T / (t_graph or t_dec), "ms_per_token": (t_graph or t_dec) / T * 1e3, "tokens": T,
+                   "ms_per_token_hip_graph": (t_graph / T * 1e3) if t_graph else None,
+                   "ms_per_token_per_layer_hooks": t_dec / T * 1e3,
+                   "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded; "
+                           "ms_per_token = the step replayed as one HIP graph (EvictCache.decode_graph), ms_per_token_per_layer_hooks = "
+                           "the same step issued layer by layer from Python (kv.update_attend, what kvzip_amd.attn does)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], parity = cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores)

@@ -271,9 +271,13 @@ size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max
  * cache object does: one D2H copy per prune).  With it the kernel gets the head segments as launch arguments and does not start
  * with a dependent load of the device arrays.  Up to 64 heads; ignored beyond.
  * ws: kvz_varlen_attn_workspace_bytes(...) bytes of scratch (partial results of the key ranges, or of the key splits of the
- * multi-row kernel); no initialisation needed, the size does not depend on max_len_k. */
+ * multi-row kernel); no initialisation needed, the size does not depend on max_len_k.
+ * k_len_offset_dev (optional, device int32): added to k_len_offset INSIDE the kernels.  A generation step captured in a HIP graph
+ * is replayed with unchanged arguments, so the part of the appended-token count that changes from token to token lives on the
+ * device (kvz_add_i32 advances it as the last node of the step); decode calls only (q_len*G <= 64 rows). */
 int kvz_varlen_attn(const void* q, const void* k, const void* v,
-                    const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
+                    const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_len_offset_dev,
+                    const int32_t* k_meta_host,
                     int Hkv, int G, int q_len, int D, int max_len_k,
                     float scale, int causal, int dtype,
                     void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
@@ -289,9 +293,13 @@ int kvz_varlen_attn(const void* q, const void* k, const void* v,
 int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache,
                            const void* k_state, const void* v_state,
                            int64_t k_state_head_stride, int64_t v_state_head_stride,
-                           const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
+                           const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_len_offset_dev,
+                           const int32_t* k_meta_host,
                            int Hkv, int G, int D, int max_len_k, float scale, int dtype,
                            void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+/* *p += delta on the stream (the device-side token counter of a captured generation step, see kvz_varlen_attn). */
+int kvz_add_i32(int32_t* p, int delta, kvz_stream_t stream);
 
 /* f2 + a13 with q_len > 1: causal GQA attention of R = q_len*G query rows per KV head over that head's key segment, keys
  * walked once per 128-row block (LDS-shared 64-key tiles, MFMA 16x16x32, online softmax).  Replaces

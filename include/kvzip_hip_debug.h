@@ -20,6 +20,10 @@ int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* u
 /* test hook, host only: n / d and n % d as the kernels compute them (multiply-shift by a launch-invariant divisor). */
 int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 
+/* test / tuning hook: set a tuning knob of the library ("attn_items", "flash_min_rows", "flash2_min_blocks"; value <= 0 restores
+ * the default) and return its previous value (< 0: unknown name).  Process-wide, not thread-safe: for tests and probes. */
+int kvz_debug_set_tunable(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

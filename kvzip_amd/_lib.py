@@ -41,6 +41,7 @@ SIGNATURES = {
     "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_debug_fastdiv": (_i, [_i, _i, _vp, _vp]),
+    "kvz_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "kvz_debug_score_plan": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -56,9 +57,10 @@ SIGNATURES = {
     "kvz_update_flatten_view": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "kvz_append_inplace": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "kvz_varlen_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
-    "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp,
+    "kvz_varlen_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "kvz_varlen_attn_append": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp,
                                     _sz, _vp]),
+    "kvz_add_i32": (_i, [_vp, _i, _vp]),
     "kvz_flash_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "kvz_flash_fwd": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _i64, _i64,
                            _i64, _vp, _vp, _sz, _vp]),

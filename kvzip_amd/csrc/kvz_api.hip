@@ -2,6 +2,8 @@
 // C ABI (include/kvzip_hip.h).
 #include "kvz_common.h"
 
+#include <string.h>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -83,6 +85,29 @@ static void prof_collect() {
     }
 }
 }  // namespace kvz
+
+// ---- tuning knobs --------------------------------------------------------------------------------------------------------
+namespace kvz {
+static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks"};
+// attn_items: work items the key ranges of a decode call are cut into (128 / 192 / 256 / 384 measured in round 2,
+//   profiles/r2_attn_items.txt: 192 is best or within 1 % of the best on uniform, AdaKV-ragged and head-level caches);
+// flash_min_rows: query rows per head above which the multi-row kernels take over from the split-key decode kernel;
+// flash2_min_blocks: (head, 256-row tile) blocks from which the 32-row dense forward is used instead of the 16-row one.
+static const int g_tune_default[TUNE_COUNT] = {192, 64, 128};
+static int g_tune[TUNE_COUNT] = {192, 64, 128};
+int tunable(Tunable t) { return g_tune[t]; }
+}  // namespace kvz
+extern "C" int kvz_debug_set_tunable(const char* name, int value) {
+    KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_set_tunable: null name");
+    for (int i = 0; i < kvz::TUNE_COUNT; ++i)
+        if (strcmp(name, kvz::g_tune_name[i]) == 0) {
+            const int prev = kvz::g_tune[i];
+            kvz::g_tune[i] = value > 0 ? value : kvz::g_tune_default[i];
+            return prev;
+        }
+    kvz::set_error("kvz_debug_set_tunable: unknown knob '%s'", name);
+    return KVZ_EINVAL;
+}
 
 extern "C" int kvz_abi_version(void) { return KVZ_ABI_VERSION; }
 extern "C" const char* kvz_last_error(void) { return kvz::g_err; }

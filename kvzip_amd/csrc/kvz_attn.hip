@@ -14,7 +14,6 @@
 //   ds_read_b64_tr_b16.  The last block of a head to finish merges the head's partials.
 #include "kvz_common.h"
 
-#include <stdlib.h>
 
 namespace kvz {
 
@@ -68,11 +67,13 @@ struct HeadMeta { int32_t start[AT_MAXH]; int32_t len[AT_MAXH]; };
 template <typename T, int D, bool APPEND, bool HOSTMETA>
 __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
     const T* __restrict__ q, const T* k, const T* v, const int32_t* __restrict__ k_start, const int32_t* __restrict__ k_len,
-    int k_len_offset, HeadMeta hm, int Hkv, int G, int q_len, int target_items, float scale, int causal, float* part_o,
-    float* part_ml, uint32_t* counters, int n_rtiles, T* __restrict__ out, const T* __restrict__ k_new,
+    int k_len_offset, const int32_t* __restrict__ k_len_offset_dev, HeadMeta hm, int Hkv, int G, int q_len, int target_items, float scale,
+    int causal, float* part_o, float* part_ml, uint32_t* counters, int n_rtiles, T* __restrict__ out, const T* __restrict__ k_new,
     const T* __restrict__ v_new, int64_t kn_head_stride, int64_t vn_head_stride) {
     typedef AttnCfg<D> C;
     typedef typename HalfTraits<T>::v8 v8;
+    // (the part of the appended-token count that lives on the DEVICE: a captured generation step is replayed with unchanged arguments)
+    if (k_len_offset_dev) k_len_offset += *k_len_offset_dev;
     auto len_of = [&](int hh) -> int { return (HOSTMETA ? hm.len[hh] : k_len[hh]) + k_len_offset; };
     // ---- this block's work item: (head, key range) from the ragged lengths (all wave-uniform scalar work) ----
     int total = 0;
@@ -271,9 +272,11 @@ template <typename T, int D, bool HOSTMETA>
 __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine2_kernel(const float* __restrict__ part_o,
                                                                          const float* __restrict__ part_ml,
                                                                          const int32_t* __restrict__ k_len, int k_len_offset,
+                                                                         const int32_t* __restrict__ k_len_offset_dev,
                                                                          HeadMeta hm, int Hkv, int G, int q_len, int target_items,
                                                                          int n_rtiles, T* __restrict__ out) {
     constexpr int SLICES = CB_THREADS / D;
+    if (k_len_offset_dev) k_len_offset += *k_len_offset_dev;
     const int h = blockIdx.x, rt = blockIdx.y, qq = blockIdx.z;
     const int R = q_len * G;
     if (rt * AT_RT + qq >= R) return;
@@ -385,15 +388,9 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine2_kernel(const 
     }
 }
 
-static inline int attn_items() {
-    static int items = 0;
-    if (!items) {
-        const char* e = getenv("KVZ_ATTN_ITEMS");  // tuning knob (work items the key ranges are cut into)
-        items = e ? atoi(e) : 192;  // 128 / 192 / 256 / 384 measured in round 2 (profiles/r2_attn_items.txt): 192 is best or within
-        if (items < 1) items = 192;  // 1 % of the best on uniform, AdaKV-ragged and head-level caches
-    }
-    return items;
-}
+__global__ void add_i32_kernel(int32_t* p, int delta) { *p += delta; }
+
+static inline int attn_items() { return tunable(TUNE_ATTN_ITEMS); }
 static inline size_t align256a(size_t x) { return (x + 255) & ~(size_t)255; }
 struct AttnWs { uint32_t* counters; float* part_ml; float* part_o; size_t bytes; };
 static inline AttnWs attn_ws(void* ws, int Hkv, int n_rtiles, int D) {
@@ -412,7 +409,7 @@ static inline AttnWs attn_ws(void* ws, int Hkv, int n_rtiles, int D) {
 
 template <typename T, int D>
 static int launch_attn(const void* q, const void* k, const void* v, const int32_t* k_start, const int32_t* k_len,
-                       int k_len_offset, const int32_t* meta_host, int Hkv, int G, int q_len, float scale, int causal, void* out,
+                       int k_len_offset, const int32_t* off_dev, const int32_t* meta_host, int Hkv, int G, int q_len, float scale, int causal, void* out,
                        void* ws, hipStream_t stream, const void* k_new = nullptr, const void* v_new = nullptr,
                        int64_t kn_stride = 0, int64_t vn_stride = 0) {
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
@@ -426,7 +423,7 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
     ProfScope ps("varlen_attn", stream);
 #define KVZ_ATTN_LAUNCH(APP, HOST)                                                                                                \
     hipLaunchKernelGGL((varlen_attn_split2_kernel<T, D, APP, HOST>), grid, block, 0, stream, reinterpret_cast<const T*>(q),          \
-                       reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v), k_start, k_len, k_len_offset, hm, Hkv, G,     \
+                       reinterpret_cast<const T*>(k), reinterpret_cast<const T*>(v), k_start, k_len, k_len_offset, off_dev, hm, Hkv, G, \
                        q_len, target, scale, causal, w.part_o, w.part_ml, w.counters, n_rtiles, reinterpret_cast<T*>(out),          \
                        reinterpret_cast<const T*>(k_new), reinterpret_cast<const T*>(v_new), kn_stride, vn_stride)
     if (k_new) { if (host) KVZ_ATTN_LAUNCH(true, true); else KVZ_ATTN_LAUNCH(true, false); }
@@ -436,10 +433,10 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
     const dim3 cgrid(Hkv, n_rtiles, AT_RT), cblock(CB_THREADS);
     if (host)
         hipLaunchKernelGGL((varlen_attn_combine2_kernel<T, D, true>), cgrid, cblock, 0, stream, w.part_o, w.part_ml, k_len, k_len_offset,
-                           hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
+                           off_dev, hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
     else
         hipLaunchKernelGGL((varlen_attn_combine2_kernel<T, D, false>), cgrid, cblock, 0, stream, w.part_o, w.part_ml, k_len, k_len_offset,
-                           hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
+                           off_dev, hm, Hkv, G, q_len, target, n_rtiles, reinterpret_cast<T*>(out));
     KVZ_CHECK_LAUNCH("varlen_attn_combine2_kernel");
     return KVZ_OK;
 }
@@ -448,15 +445,8 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
 
 using namespace kvz;
 
-// query rows per head above which the multi-row kernel takes over from the split-key decode kernel (KVZ_FLASH_MIN_ROWS)
-static int flash_min_rows() {
-    static const int v = [] {
-        const char* e = getenv("KVZ_FLASH_MIN_ROWS");
-        const int x = e ? atoi(e) : 0;
-        return x > 0 ? x : 64;
-    }();
-    return v;
-}
+// query rows per head above which the multi-row kernel takes over from the split-key decode kernel
+static int flash_min_rows() { return tunable(TUNE_FLASH_MIN_ROWS); }
 
 extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int D, int max_len_k) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0 || max_len_k < 0) return 0;
@@ -466,7 +456,7 @@ extern "C" size_t kvz_varlen_attn_workspace_bytes(int Hkv, int G, int q_len, int
 }
 
 extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, const int32_t* k_start,
-                               const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int q_len,
+                               const int32_t* k_len, int k_len_offset, const int32_t* k_len_offset_dev, const int32_t* k_meta_host, int Hkv, int G, int q_len,
                                int D, int max_len_k, float scale,
                                int causal, int dtype, void* out, void* ws, size_t ws_bytes, kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -477,6 +467,7 @@ extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, cons
     KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ws), KVZ_EINVAL,
                 "kvz_varlen_attn: q/k/v/ws must be 16-byte aligned");
     if (q_len * G > flash_min_rows()) {  // many query rows: one pass over the keys per 128-row block (kvz_flash.hip)
+        KVZ_REQUIRE(k_len_offset_dev == nullptr, KVZ_EUNSUPPORTED, "kvz_varlen_attn: a device-side offset is a decode-step feature (q_len*G <= %d rows)", flash_min_rows());
         KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
                     "kvz_varlen_attn: workspace too small");
         return kvz_flash_fwd(q, (int64_t)q_len * G * D, D, (int64_t)G * D, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G,
@@ -487,18 +478,18 @@ extern "C" int kvz_varlen_attn(const void* q, const void* k, const void* v, cons
     KVZ_REQUIRE(ws_bytes >= kvz_varlen_attn_workspace_bytes(Hkv, G, q_len, D, max_len_k), KVZ_EWORKSPACE,
                 "kvz_varlen_attn: workspace too small");
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
-        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+        if (D == 128) return launch_attn<_Float16, 128>(q, k, v, k_start, k_len, k_len_offset, k_len_offset_dev, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+        return launch_attn<_Float16, 64>(q, k, v, k_start, k_len, k_len_offset, k_len_offset_dev, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
     }
-    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
-    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+    if (D == 128) return launch_attn<__bf16, 128>(q, k, v, k_start, k_len, k_len_offset, k_len_offset_dev, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
+    return launch_attn<__bf16, 64>(q, k, v, k_start, k_len, k_len_offset, k_len_offset_dev, k_meta_host, Hkv, G, q_len, scale, causal, out, ws, stream);
 }
 
 extern "C" int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache, const void* k_state, const void* v_state,
                                       int64_t k_state_head_stride, int64_t v_state_head_stride, const int32_t* k_start,
-                                      const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int D,
-                                      int max_len_k, float scale, int dtype, void* out, void* ws, size_t ws_bytes,
-                                      kvz_stream_t stream_) {
+                                      const int32_t* k_len, int k_len_offset, const int32_t* k_len_offset_dev,
+                                      const int32_t* k_meta_host, int Hkv, int G, int D, int max_len_k, float scale, int dtype, void* out,
+                                      void* ws, size_t ws_bytes, kvz_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k_cache && v_cache && k_state && v_state && k_start && k_len && out && ws, KVZ_EINVAL,
                 "kvz_varlen_attn_append: null pointer");
@@ -513,9 +504,19 @@ extern "C" int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cach
                 "kvz_varlen_attn_append: workspace too small");
     const int off = k_len_offset + 1;  // the keys attended to include the token appended by this call
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_attn<_Float16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
-        return launch_attn<_Float16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+        if (D == 128) return launch_attn<_Float16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_len_offset_dev, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+        return launch_attn<_Float16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_len_offset_dev, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
     }
-    if (D == 128) return launch_attn<__bf16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
-    return launch_attn<__bf16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    if (D == 128) return launch_attn<__bf16, 128>(q, k_cache, v_cache, k_start, k_len, off, k_len_offset_dev, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+    return launch_attn<__bf16, 64>(q, k_cache, v_cache, k_start, k_len, off, k_len_offset_dev, k_meta_host, Hkv, G, 1, scale, 1, out, ws, stream, k_state, v_state, k_state_head_stride, v_state_head_stride);
+}
+
+
+// the device-side part of the appended-token count (k_len_offset_dev of the attention calls): += delta, one tiny launch - the last
+// node of a captured generation step
+extern "C" int kvz_add_i32(int32_t* p, int delta, kvz_stream_t stream_) {
+    KVZ_REQUIRE(p && (reinterpret_cast<uintptr_t>(p) & 3u) == 0, KVZ_EINVAL, "kvz_add_i32: bad pointer");
+    hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, p, delta);
+    KVZ_CHECK_LAUNCH("add_i32_kernel");
+    return KVZ_OK;
 }

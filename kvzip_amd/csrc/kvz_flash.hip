@@ -315,6 +315,9 @@ extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_str
                 "kvz_flash_fwd: query strides must be multiples of 8 elements");
     KVZ_REQUIRE(o_stride_head % 4 == 0 && o_stride_group % 4 == 0 && o_stride_pos % 4 == 0, KVZ_EINVAL,
                 "kvz_flash_fwd: output strides must be multiples of 4 elements");
+    if (flash2_takes(Hkv, G, q_len, D) && (k_meta_host == nullptr || Hkv <= FL_MAXH))
+        return flash2_fwd(q, q_stride_head, q_stride_group, q_stride_pos, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len,
+                          scale, causal, dtype, out, o_stride_head, o_stride_group, o_stride_pos, lse_out, (hipStream_t)stream_);
     FlashArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.lse = lse_out;
     a.k_start = k_start; a.k_len = k_len; a.k_len_offset = k_len_offset;

@@ -232,6 +232,9 @@ class EvictCache(_CacheBase):
         self.verbose = verbose
         self.info: Dict[str, Any] = {"flatten": False, "offset": None}
         self._attn_ws: Optional[torch.Tensor] = None
+        self._dyn_off: Optional[torch.Tensor] = None   # device part of the appended-token count (graph-captured generation steps)
+        self._dyn_val = 0                              # ... and what it holds, as the host knows it
+        self._layout_epoch = 0                         # bumped whenever the flat cache moves (captured graphs hold its addresses)
 
     # reference: kvcache.py:41-80
     def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=dict()):
@@ -319,6 +322,7 @@ class EvictCache(_CacheBase):
         self.key_cache, self.value_cache = list(ks), list(vs)
         self._store_k, self._store_v, self._fill = [], [], []  # release the dense storage
         self._views.clear()
+        self._layout_epoch = getattr(self, "_layout_epoch", 0) + 1
         self._plan = plan
         cu_head = torch.arange(Hkv + 1, dtype=torch.int32, device=self.device)
         self.info = {
@@ -366,6 +370,7 @@ class EvictCache(_CacheBase):
             self.key_cache[l], self.value_cache[l] = nk, nv
             self.info["seg_start"][l] = torch.tensor(starts, dtype=torch.int32, device=self.device)
         self.slack = new_slack
+        self._layout_epoch += 1
         self._refresh_meta_host()
 
     # reference: kvcache.py:187-213
@@ -428,7 +433,7 @@ class EvictCache(_CacheBase):
         return mh[layer_idx] if mh is not None else None
 
     def update_attend(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int,
-                      softmax_scale: Optional[float] = None) -> torch.Tensor:
+                      softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Decode step (one new token) on the pruned cache, slack layout: ``update`` + ``prepare`` + ``attend`` in one
         launch of the attention kernel, which also writes the token's K, V row into the slack of every head.
         query ``[1, H, 1, D]``, key / value ``[1, Hkv, 1, D]``; returns ``[Hkv, G, D]`` like ``attend``.  The cache
@@ -442,12 +447,80 @@ class EvictCache(_CacheBase):
         dim = query_states.shape[-1]
         max_len_k = self.info["max_len_k"][layer_idx] + off + 1
         ws = self._attn_workspace(1, dim, query_states.device)
+        # (the appended-token count = host part + device part: see decode_graph; without a graph there is no device part)
+        if self._dyn_off is not None and off < self._dyn_val:  # (after slice(): the device part restarts with the host's count)
+            self._sync_dyn(off)
         out = ops.varlen_attn_append(query_states.reshape(-1, self.n_group_kv, dim), self.key_cache[layer_idx],
                                      self.value_cache[layer_idx], key_states, value_states,
-                                     self.info["seg_start"][layer_idx], self.info["len_k"][layer_idx], off, max_len_k,
-                                     softmax_scale=softmax_scale, workspace=ws, meta_host=self._meta_host(layer_idx))
+                                     self.info["seg_start"][layer_idx], self.info["len_k"][layer_idx], off - self._dyn_val, max_len_k,
+                                     softmax_scale=softmax_scale, workspace=ws, meta_host=self._meta_host(layer_idx),
+                                     offset_dev=self._dyn_off, out=out)
         self.info["offset"][layer_idx] = off + 1
         return out
+
+    # ---- a whole generation step as ONE HIP graph ---------------------------------------------------------------------------
+    def decode_graph(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, softmax_scale: Optional[float] = None):
+        """Capture the attention part of ONE generation step over all layers - L x (append the token's K,V + variable-length
+        attention) - into a HIP graph and return a ``DecodeGraph``; ``replay()`` runs the step for the tensors that are in the
+        static buffers at that moment (``query [L, 1, H, 1, D]``, ``key`` / ``value [L, 1, Hkv, 1, D]``; outputs in ``.out``
+        ``[L, Hkv, G, D]``).  Replays need unchanged kernel arguments, so the part of the appended-token count that changes from
+        token to token lives in a device counter that the last node of the graph advances (``k_len_offset_dev``); the host
+        bookkeeping (``info["offset"]``, ``_seen_tokens``) advances in ``replay()``.  What a serving engine does with its
+        static input buffers; the per-layer hooks of a Python forward pass (``update_attend``) stay available beside it."""
+        assert self.info["flatten"] and self.layout == "slack"
+        L = self.n_layers
+        assert query.shape[0] == L and key.shape[0] == L and value.shape[0] == L and query.shape[-2] == 1
+        lib = ops._lib.load()
+        offsets0, seen0 = list(self.info["offset"]), self._seen_tokens
+        assert min(offsets0) == max(offsets0), "a generation step starts with the same number of appended tokens in every layer"
+        if offsets0[0] + 2 > self.slack:
+            self._grow_slack(offsets0[0] + 2)
+        if self._dyn_off is None:
+            self._dyn_off = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._sync_dyn(offsets0[0])   # the WHOLE count lives on the device from here on: the captured host part is 0
+        out = torch.empty((L, self.n_heads_kv, self.n_group_kv, query.shape[-1]), dtype=query.dtype, device=query.device)
+        self._attn_workspace(1, query.shape[-1], query.device)
+        dyn0 = self._dyn_val
+        torch.cuda.synchronize(query.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for l in range(L):
+                self.update_attend(query[l], key[l], value[l], l, softmax_scale=softmax_scale, out=out[l])
+            ops.check(lib.kvz_add_i32(self._dyn_off.data_ptr(), 1, ops._stream(self._dyn_off)), "kvz_add_i32")
+        # (capturing executes nothing: the host bookkeeping goes back to where it was)
+        self.info["offset"], self._seen_tokens, self._dyn_val = offsets0, seen0, dyn0
+        return DecodeGraph(self, graph, out)
+
+    def _sync_dyn(self, value: int):
+        """device part of the appended-token count := value (one fill on the current stream)"""
+        if self._dyn_val != value or value == 0:
+            self._dyn_off.fill_(value)
+            self._dyn_val = value
+
+
+class DecodeGraph:
+    """One captured generation step of an ``EvictCache`` (see ``EvictCache.decode_graph``)."""
+
+    def __init__(self, kv: "EvictCache", graph, out: torch.Tensor):
+        self.kv, self.graph, self.out = kv, graph, out
+        self.epoch = kv._layout_epoch
+
+    def replay(self) -> torch.Tensor:
+        kv = self.kv
+        off = kv.info["offset"]
+        if self.epoch != kv._layout_epoch:
+            raise ops.KvzError("decode graph: the flat cache was re-laid out since the capture (prune / slack growth): capture again")
+        if max(off) + 1 > kv.slack:
+            raise ops.KvzError("decode graph: the slack of the head segments is used up (the graph holds the addresses of the flat "
+                               "cache: grow the slack and capture again)")
+        assert min(off) == max(off)
+        if off[0] != kv._dyn_val:  # (tokens appended by the per-layer hooks, or slice(), since the last replay)
+            kv._sync_dyn(off[0])
+        self.graph.replay()
+        kv.info["offset"] = [o + 1 for o in off]
+        kv._seen_tokens += 1
+        kv._dyn_val += 1
+        return self.out
 
 
 class RetainCache(_CacheBase):

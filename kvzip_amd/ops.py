@@ -351,7 +351,8 @@ def _meta_host(k_start_host, k_len_host, Hkv):
 
 def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor,
                 q_len: int, max_len_k: int, causal: bool = True, softmax_scale: Optional[float] = None,
-                workspace: Optional[torch.Tensor] = None, k_len_offset: int = 0, meta_host=None) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, k_len_offset: int = 0, meta_host=None,
+                offset_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q ``[Hkv*q_len, G, D]``; k, v ``[rows, D]`` (or ``[rows, 1, D]``); head h owns rows
     ``k_start[h] : k_start[h]+k_len[h]``.  Returns ``[Hkv*q_len, G, D]``.  ``meta_host``: ctypes array from
     ``_meta_host`` (the segments as the host knows them) or None; ``workspace`` from ``attn_workspace``."""
@@ -362,11 +363,12 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
     assert k_start.dtype == torch.int32 and k_len.dtype == torch.int32
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
-    out = torch.empty_like(q)
+    if out is None:
+        out = torch.empty_like(q)
     if workspace is None:  # (a caller-provided workspace is validated by the library itself: KVZ_EWORKSPACE)
         workspace = attn_workspace(Hkv, G, q_len, D, q.device)
     rc = lib.kvz_varlen_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), k_start.data_ptr(), k_len.data_ptr(),
-                             int(k_len_offset), meta_host, Hkv, G,
+                             int(k_len_offset), _ptr(offset_dev), meta_host, Hkv, G,
                              q_len, D, int(max_len_k), float(scale), 1 if causal else 0, _dtype_code(q.dtype),
                              out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
     check(rc, "kvz_varlen_attn")
@@ -376,7 +378,7 @@ def varlen_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_start: torc
 def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k_state: torch.Tensor,
                        v_state: torch.Tensor, k_start: torch.Tensor, k_len: torch.Tensor, k_len_offset: int, max_len_k: int,
                        softmax_scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None,
-                       meta_host=None) -> torch.Tensor:
+                       meta_host=None, offset_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Decode step in one launch: append the new token's K, V (``[1, Hkv, 1, D]``, any head stride) to the per-head slack
     of the flat cache and attend ``q`` (``[Hkv, G, D]``) over ``k_len + k_len_offset + 1`` keys.  ``k_len_offset`` counts the
     tokens appended BEFORE this call.  Bit-identical to ``append_inplace`` followed by ``varlen_attn``."""
@@ -386,12 +388,13 @@ def varlen_attn_append(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Te
     assert k_state.stride(-1) == 1 and v_state.stride(-1) == 1 and q.is_contiguous()
     assert k_start.dtype == torch.int32 and k_len.dtype == torch.int32
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
-    out = torch.empty_like(q)
+    if out is None:
+        out = torch.empty_like(q)
     if workspace is None:
         workspace = attn_workspace(Hkv, G, 1, D, q.device)
     rc = lib.kvz_varlen_attn_append(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_state.data_ptr(),
                                     v_state.data_ptr(), k_state.stride(-3), v_state.stride(-3), k_start.data_ptr(),
-                                    k_len.data_ptr(), int(k_len_offset), meta_host, Hkv, G, D, int(max_len_k), float(scale),
+                                    k_len.data_ptr(), int(k_len_offset), _ptr(offset_dev), meta_host, Hkv, G, D, int(max_len_k), float(scale),
                                     _dtype_code(q.dtype), out.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q))
     check(rc, "kvz_varlen_attn_append")
     return out

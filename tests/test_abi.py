@@ -71,7 +71,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.kvz_select_threshold(None, 10, 0.3, 0, None, 10, None, None, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.kvz_last_error()
-    rc = lib.kvz_varlen_attn(16, 16, 16, 16, 16, 0, None, 2, 7, 1, 96, 10, 0.1, 1, 0, 16, 16, 1 << 30, None)
+    rc = lib.kvz_varlen_attn(16, 16, 16, 16, 16, 0, None, None, 2, 7, 1, 96, 10, 0.1, 1, 0, 16, 16, 1 << 30, None)
     assert rc == -4 and b"head_dim" in lib.kvz_last_error()
     with pytest.raises(_lib.KvzError):
         _lib.check(rc, "kvz_varlen_attn")

@@ -313,3 +313,65 @@ def test_update_attend_equals_update_prepare_attend(dtype):
         for h in range(Hkv):
             assert torch.equal(a.key_cache[l][seg[h]:seg[h] + lens[h]], b.key_cache[l][seg[h]:seg[h] + lens[h]])
             assert torch.equal(a.value_cache[l][seg[h]:seg[h] + lens[h]], b.value_cache[l][seg[h]:seg[h] + lens[h]])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decode_graph_equals_per_layer_hooks(dtype):
+    """A generation step captured in ONE HIP graph (EvictCache.decode_graph: L x (append + attention) + the device-side token
+    counter) against the per-layer hook of the Python forward pass (update_attend): outputs, cache rows and bookkeeping bit-identical
+    over several tokens, across a slice() (multi-query reuse), with hook steps and graph replays interleaved, and the graph must
+    refuse to run once the flat cache has been re-laid out."""
+    from kvzip_amd import ops
+    from kvzip_amd.kvcache import EvictCache
+    L, H, Hkv, D, sink, N = 3, 14, 2, 128, 8, 1500
+    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
+    g = torch.Generator(device=DEV).manual_seed(77)
+
+    def make():
+        gg = torch.Generator(device=DEV).manual_seed(5)
+        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dtype, verbose=False, slack=64)
+        for l in range(L):
+            kv.update(torch.randn(1, Hkv, sink + N, D, generator=gg, device=DEV).to(dtype),
+                      torch.randn(1, Hkv, sink + N, D, generator=gg, device=DEV).to(dtype), l)
+        kv.score = [torch.rand(1, Hkv, N, generator=gg, device=DEV).to(dtype) for _ in range(L)]
+        kv.prune(0.35)
+        return kv
+
+    a, b = make(), make()
+    qb = torch.empty(L, 1, H, 1, D, dtype=dtype, device=DEV)
+    kb = torch.empty(L, 1, Hkv, 1, D, dtype=dtype, device=DEV)
+    vb = torch.empty(L, 1, Hkv, 1, D, dtype=dtype, device=DEV)
+    seen0 = a._seen_tokens
+    step_graph = None
+
+    def one_token(use_graph):
+        qb.copy_(torch.randn(qb.shape, generator=g, device=DEV).to(dtype))
+        kb.copy_(torch.randn(kb.shape, generator=g, device=DEV).to(dtype))
+        vb.copy_(torch.randn(vb.shape, generator=g, device=DEV).to(dtype))
+        want = torch.stack([a.update_attend(qb[l], kb[l], vb[l], l) for l in range(L)])
+        if use_graph:
+            got = step_graph.replay().clone()
+        else:
+            got = torch.stack([b.update_attend(qb[l], kb[l], vb[l], l) for l in range(L)])
+        assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+        assert a._seen_tokens == b._seen_tokens and a.info["offset"] == b.info["offset"]
+
+    one_token(False)                      # a token through the hooks first: the graph is captured mid-generation
+    step_graph = b.decode_graph(qb, kb, vb)
+    assert b.info["offset"] == a.info["offset"] and b._seen_tokens == a._seen_tokens  # capturing executes nothing
+    for _ in range(5):
+        one_token(True)
+    one_token(False)                      # hooks and replays interleave (the device counter is re-synchronised)
+    one_token(True)
+    a.slice(seen0); b.slice(seen0)        # next query on the same compressed context
+    for _ in range(3):
+        one_token(True)
+    for l in range(L):
+        seg = a.info["seg_start"][l].tolist()
+        lens = (a.info["len_k"][l] + a.info["offset"][l]).tolist()
+        for h in range(Hkv):
+            assert torch.equal(a.key_cache[l][seg[h]:seg[h] + lens[h]], b.key_cache[l][seg[h]:seg[h] + lens[h]])
+            assert torch.equal(a.value_cache[l][seg[h]:seg[h] + lens[h]], b.value_cache[l][seg[h]:seg[h] + lens[h]])
+    b._grow_slack(200)
+    with pytest.raises(ops.KvzError):
+        step_graph.replay()

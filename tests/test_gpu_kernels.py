@@ -634,21 +634,20 @@ def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
         assert ((got - want).abs() <= tol + rel * want.abs()).all(), float((got - want).abs().max())
     # the decode kernel (16-row tiles, split keys) must agree with the multi-row kernel on the same call
     if q_len == 64:
-        import os
-        import subprocess
-        import sys
-        code = ("import torch, sys; sys.path.insert(0, %r); from kvzip_amd import ops; torch.manual_seed(0);"
-                "q=torch.randn(4*64,7,128,device='cuda').half(); k=torch.randn(9000,128,device='cuda').half();"
-                "v=torch.randn(9000,128,device='cuda').half(); ks=torch.tensor([0,3000,5000,8000],dtype=torch.int32,device='cuda');"
-                "kl=torch.tensor([2900,1900,2500,64],dtype=torch.int32,device='cuda');"
-                "o=ops.varlen_attn(q,k,v,ks,kl,64,2900); print(float(o.float().abs().sum()))" % ROOT)
+        lib = ops._lib.load()
+        torch.manual_seed(0)
+        q2 = torch.randn(4 * 64, 7, 128, device=DEV).to(dtype); k2 = torch.randn(9000, 128, device=DEV).to(dtype)
+        v2 = torch.randn(9000, 128, device=DEV).to(dtype)
+        ks2 = torch.tensor([0, 3000, 5000, 8000], dtype=torch.int32, device=DEV)
+        kl2 = torch.tensor([2900, 1900, 2500, 64], dtype=torch.int32, device=DEV)
         outs = []
-        for rows in ("64", "100000"):
-            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
-                               env={**os.environ, "KVZ_FLASH_MIN_ROWS": rows})
-            assert r.returncode == 0, r.stderr[-800:]
-            outs.append(float(r.stdout.strip().splitlines()[-1]))
-        assert abs(outs[0] - outs[1]) <= 2e-4 * abs(outs[1]), outs
+        for rows in (64, 100000):
+            prev = lib.kvz_debug_set_tunable(b"flash_min_rows", rows)
+            try:
+                outs.append(ops.varlen_attn(q2, k2, v2, ks2, kl2, 64, 2900).float())
+            finally:
+                lib.kvz_debug_set_tunable(b"flash_min_rows", prev)
+        assert (outs[0] - outs[1]).abs().max() <= tol + rel * outs[1].abs().max(), float((outs[0] - outs[1]).abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -680,6 +679,46 @@ def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
     from kvzip_amd.attn import dense_causal_attention
     out2, _ = dense_causal_attention(None, qq, key, val, scaling=1.0 / math.sqrt(D))
     assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(28, 4, 300, 300), (28, 4, 130, 1500), (8, 2, 257, 1000), (6, 2, 70, 77), (16, 16, 129, 700), (7, 1, 1100, 2300)])
+def test_flash2_dense_vs_fp32_reference(shape, dtype):
+    """The 32-row forward (kvz_flash2.hip: 256-row blocks, 32x32x16 MFMA, LDS-DMA ring) forced onto shapes of every kind - several
+    row tiles, a partial last row tile, fewer keys than a tile, a ragged last key tile, G = 1 and Hkv = 1, rows that see a single key -
+    against an fp32 reference with the same bottom-right mask, and against the 16-row kernel on the same call."""
+    from kvzip_amd import ops
+    lib = ops._lib.load()
+    H, Hkv, q_len, klen = shape
+    D, G = 128, shape[0] // shape[1]
+    g = torch.Generator(device=DEV).manual_seed(q_len * 7 + klen)
+    cap = klen + 19
+    kc = torch.randn(1, Hkv, cap, D, generator=g, device=DEV).to(dtype)
+    vc = torch.randn(1, Hkv, cap, D, generator=g, device=DEV).to(dtype)
+    qq = torch.randn(1, q_len, H, D, generator=g, device=DEV).to(dtype).transpose(1, 2)
+    key, val = kc[:, :, :klen], vc[:, :, :klen]
+    prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    try:
+        out, lse = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+        again, _ = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1 << 30)
+    try:
+        old, lse_old = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)   # the 16-row kernel
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
+    assert torch.equal(out, again)
+    s = torch.einsum("hid,hjd->hij", qq[0].float(), key[0].float().repeat_interleave(G, 0)) / math.sqrt(D)
+    i = torch.arange(q_len, device=DEV).view(1, q_len, 1)
+    j = torch.arange(klen, device=DEV).view(1, 1, klen)
+    s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
+    want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
+    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    err = (out[0].float() - want).abs()
+    print(f"\nflash2 {shape} {dtype}: max |err| {float(err.max()):.2e} (16-row kernel: {float((old[0].float() - want).abs().max()):.2e})")
+    assert (err <= tol + rel * want.abs()).all(), float(err.max())
+    assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
+    assert ((out.float() - old.float()).abs() <= 2 * (tol + rel * want.abs().unsqueeze(0))).all()
 
 
 def test_flash_attn_varlen_func_call_compatibility():

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "kvzip_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "ab")
 os.makedirs(OUT, exist_ok=True)
-SRCS = ["kvz_api.hip", "kvz_select.hip", "kvz_compact.hip", "kvz_score.hip", "kvz_attn.hip", "kvz_flash.hip"]
+SRCS = ["kvz_api.hip", "kvz_select.hip", "kvz_compact.hip", "kvz_score.hip", "kvz_attn.hip", "kvz_flash.hip", "kvz_flash2.hip"]
 base_objs = {s: os.path.join(CS, s.replace(".hip", ".o")) for s in SRCS}
 for spec in sys.argv[1:]:
     name, _, flags = spec.partition(":")
