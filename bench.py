@@ -551,12 +551,11 @@ def main(argv=None):
         },
         "roofline": roofline,
         "roofline_stages": stages,
-        "decode": {"tokens_per_s": T / (t_graph or t_dec), "ms_per_token": (t_graph or t_dec) / T * 1e3, "tokens": T,
+        "decode": {"tokens_per_s": T / t_dec, "ms_per_token": t_dec / T * 1e3, "tokens": T,
                    "ms_per_token_hip_graph": (t_graph / T * 1e3) if t_graph else None,
-                   "ms_per_token_per_layer_hooks": t_dec / T * 1e3,
                    "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded; "
-                           "ms_per_token = the step replayed as one HIP graph (EvictCache.decode_graph), ms_per_token_per_layer_hooks = "
-                           "the same step issued layer by layer from Python (kv.update_attend, what kvzip_amd.attn does)"},
+                           "ms_per_token = the step issued layer by layer from Python (kv.update_attend, what kvzip_amd.attn does), "
+                           "ms_per_token_hip_graph = the same step replayed as one HIP graph (EvictCache.decode_graph)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], parity = cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores)

@@ -106,6 +106,18 @@ int kvz_score_chunk_async_log(int handle, int slot, kvz_stream_t caller, kvz_str
                               const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                               int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
+/* f2 ("compute the score inside the scoring forward's attention kernel"): the column-maximum pass alone, on row
+ * statistics that kvz_flash_fwd_window produced from the forward's own QK^T tiles (attention/attn.py:53-54 duplicates the QK^T of
+ * :75-89 in the reference).  stats: [Hkv, stats_head_stride] float2 = (m_r, l'_r), row g*q_len + i.  Output: the log buffer only. */
+int kvz_score_from_stats_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
+                             const float* stats, int64_t stats_head_stride,
+                             uint32_t* log_out, int64_t log_head_stride, kvz_stream_t stream);
+int kvz_score_from_stats_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
+                                   const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                                   int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
+                                   const float* stats, int64_t stats_head_stride,
+                                   uint32_t* log_out, int64_t log_head_stride);
 int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream);
 int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream);
 
@@ -297,6 +309,19 @@ int kvz_varlen_attn_append(const void* q, void* k_cache, void* v_cache,
                            const int32_t* k_meta_host,
                            int Hkv, int G, int D, int max_len_k, float scale, int dtype,
                            void* out, void* ws, size_t ws_bytes, kvz_stream_t stream);
+
+/* The dense causal forward of a SCORING pass (reference attention/attn.py:75-89 with kv.get_score set): kvz_flash_fwd on the
+ * 32-row kernel, which additionally applies the scoring rounding chain (attention/score.py:57-61) to the accumulators of the key
+ * tiles that belong to  sink ++ [win_start, win_end) ++ repeat chunk  and writes the per-row softmax statistics
+ * win_stats [Hkv, win_stats_head_stride] float2 (m_r, l'_r; row g*q_len + i) for kvz_score_from_stats_log.  Head segments by
+ * value (k_meta_host: starts then lengths, the lengths include the q_len rows of the repeat chunk).  KVZ_EUNSUPPORTED when the
+ * shape is not one the 32-row kernel takes (head_dim 128, enough row blocks): the caller then scores with kvz_score_chunk. */
+int kvz_flash_fwd_window(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos,
+                         const void* k, const void* v, const int32_t* k_meta_host,
+                         int Hkv, int G, int q_len, int D, float scale, int dtype,
+                         void* out, int64_t o_stride_head, int64_t o_stride_group, int64_t o_stride_pos,
+                         int win_sink, int win_start, int win_end, float* win_stats, int64_t win_stats_head_stride,
+                         kvz_stream_t stream);
 
 /* *p += delta on the stream (the device-side token counter of a captured generation step, see kvz_varlen_attn). */
 int kvz_add_i32(int32_t* p, int delta, kvz_stream_t stream);

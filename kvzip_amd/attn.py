@@ -23,13 +23,24 @@ def dense_causal_attention(module, query, key, value, attention_mask=None, dropo
                            scaling: Optional[float] = None, **kwargs):
     """[b, H, q, D] x [b, Hkv, k, D] -> ([b, q, H, D], None); causal mask aligned to the bottom-right corner
     (query i sees keys j <= i + k - q), like flash-attn's dense kernel used by the reference (attention/attn.py:75-89).
-    Runs on the library's own multi-row kernel (``kvz_flash_fwd``) straight off the dense cache views; torch SDPA only
-    for what that kernel does not take (CPU tensors, fp32, head dims other than 64 / 128, batch > 1)."""
+    Device tensors run on the library's own kernels (``kvz_flash_fwd``) straight off the dense cache views - and ONLY there: what
+    those kernels do not take (fp32, head dims other than 64 / 128, batch > 1, sliding-window layers, dropout) raises instead of
+    silently falling back to a generic implementation.  CPU tensors (host-logic tests, no GPU) go through torch SDPA."""
     q_len, k_len = query.shape[-2], key.shape[-2]
     G = query.shape[1] // key.shape[1]
-    if (query.is_cuda and query.dtype in (torch.float16, torch.bfloat16) and query.shape[0] == 1
-            and query.shape[-1] in (64, 128) and key.shape[1] <= 64):
+    window = kwargs.get("sliding_window", None) or getattr(module, "sliding_window", None)
+    if window is not None and k_len > window:
+        raise NotImplementedError("sliding-window attention layers (Gemma3 local layers) are outside this path: the dense kernel "
+                                  "attends globally (reference attention/attn.py:99-190 handles them with a hybrid cache)")
+    if query.is_cuda:
         from . import ops
+        if dropout:
+            raise ops.KvzError("kvz_flash_fwd has no dropout (inference path)")
+        if not (query.dtype in (torch.float16, torch.bfloat16) and query.shape[0] == 1 and query.shape[-1] in (64, 128)
+                and key.shape[1] <= 64):
+            raise ops.KvzError(f"dense attention on the device needs fp16 / bf16, batch 1, head_dim 64 or 128 and <= 64 KV heads "
+                               f"(got {query.dtype}, batch {query.shape[0]}, head_dim {query.shape[-1]}, {key.shape[1]} KV heads): "
+                               "there is no generic fallback in the product path")
         return ops.flash_fwd(query, key, value, causal=True, softmax_scale=scaling), None
     mask, causal = None, False
     if q_len == k_len:
@@ -77,10 +88,18 @@ def llama_qwen_attn_forward(self, hidden_states: torch.Tensor,
     if kv is not None:
         key_states, value_states = kv.update(key_states, value_states, self.layer_idx)
 
+    attn_output = None
     if getattr(kv, "get_score", None):  # calculate KV importance (attention/attn.py:53-54)
-        kv._get_score(query_states.contiguous(), key_states, self.layer_idx)
+        query_states = query_states.contiguous()
+        if getattr(kv, "fuse_forward_score", False) and not getattr(kv, "pruned", None):
+            # f2: ONE attention kernel produces the layer's output and the row statistics of the scores (None: shape not taken)
+            attn_output = kv._score_forward(query_states, key_states, value_states, self.layer_idx, softmax_scale=self.scaling)
+        if attn_output is None:
+            kv._get_score(query_states, key_states, self.layer_idx)
 
-    if getattr(kv, "pruned", None):     # attention with the pruned cache (attention/attn.py:56-73)
+    if attn_output is not None:
+        pass
+    elif getattr(kv, "pruned", None):     # attention with the pruned cache (attention/attn.py:56-73)
         q, k, v, info = kv.prepare(query_states.contiguous(), key_states, value_states, self.layer_idx)
         attn = kv.attend(q, k, v, info, causal=True, softmax_scale=self.scaling)      # [Hkv*q_len, G, D]
         n_kv = self.config.num_key_value_heads

@@ -271,3 +271,31 @@ extern "C" int kvz_update_score_async_log(int handle, int slot, kvz_stream_t cal
     return score_chunk_async_impl(handle, slot, caller, side, q, q_head_stride, k_cache, cache_head_stride, fill + t, sink, start, end,
                                   q_len, Hkv, G, D, dtype, log_out, log_head_stride, ws, ws_bytes, true);
 }
+
+// pass B only, asynchronously: the row statistics came out of the scoring forward (kvz_flash_fwd_window on the caller's stream)
+extern "C" int kvz_score_from_stats_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, const void* q,
+                                             int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink,
+                                             int start, int end, int q_len, int Hkv, int G, int D, int dtype, const float* stats,
+                                             int64_t stats_head_stride, uint32_t* log_out, int64_t log_head_stride) {
+    kvz::AsyncCtx* c = kvz::async_get(handle);
+    KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_from_stats_async_log: bad handle %d", handle);
+    KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_from_stats_async_log: bad slot %d", slot);
+    if (side != caller) {
+        if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess) {
+            kvz::set_error("kvz_score_from_stats_async_log: could not order the side stream behind the caller's stream");
+            return KVZ_ELAUNCH;
+        }
+    }
+    const int rc = kvz_score_from_stats_log(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, stats,
+                                            stats_head_stride, log_out, log_head_stride, side);
+    if (rc != KVZ_OK) return rc;
+    if (side != caller) {
+        if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {
+            kvz::set_error("kvz_score_from_stats_async_log: hipEventRecord failed");
+            return KVZ_ELAUNCH;
+        }
+        c->pending[slot] = 1;
+    }
+    return KVZ_OK;
+}

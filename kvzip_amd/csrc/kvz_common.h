@@ -52,12 +52,16 @@ struct ProfScope {
 enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_COUNT = 3 };
 int tunable(Tunable t);
 
+// exact-reciprocal constant of the scoring rounding chain (kvz_score.hip): half(x * r) == half(x / sqrt(D)) for every 16-bit x, or 0
+float score_exact_reciprocal(int D, int dtype);
+
 // the 32-row dense forward (kvz_flash2.hip), reached through kvz_flash_fwd
 bool flash2_takes(int Hkv, int G, int q_len, int D);
 int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k, const void* v,
                const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int q_len,
                float scale, int causal, int dtype, void* out, int64_t o_stride_head, int64_t o_stride_group, int64_t o_stride_pos,
-               float* lse_out, hipStream_t stream);
+               float* lse_out, hipStream_t stream, int win_sink = 0, int win_start = 0, int win_end = 0, float* win_stats = nullptr,
+               int64_t win_stats_head_stride = 0);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -343,3 +343,28 @@ extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_str
     if (dtype == KVZ_F16) return D == 128 ? launch_flash<_Float16, 128>(a, stream) : launch_flash<_Float16, 64>(a, stream);
     return D == 128 ? launch_flash<__bf16, 128>(a, stream) : launch_flash<__bf16, 64>(a, stream);
 }
+
+
+// f2: the dense forward of a scoring pass that also emits the row statistics of KVScore._get_score from its own QK^T tiles
+extern "C" int kvz_flash_fwd_window(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k,
+                                    const void* v, const int32_t* k_meta_host, int Hkv, int G, int q_len, int D, float scale, int dtype,
+                                    void* out, int64_t o_stride_head, int64_t o_stride_group, int64_t o_stride_pos, int win_sink,
+                                    int win_start, int win_end, float* win_stats, int64_t win_stats_head_stride, kvz_stream_t stream_) {
+    KVZ_REQUIRE(q && k && v && out && k_meta_host && win_stats, KVZ_EINVAL, "kvz_flash_fwd_window: null pointer");
+    KVZ_REQUIRE(Hkv > 0 && Hkv <= FL_MAXH && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_flash_fwd_window: bad shape");
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_flash_fwd_window: bad dtype %d", dtype);
+    KVZ_REQUIRE(flash2_takes(Hkv, G, q_len, D), KVZ_EUNSUPPORTED,
+                "kvz_flash_fwd_window: only the 32-row kernel emits the statistics (head_dim 128, >= %d row blocks)", tunable(TUNE_FLASH2_MIN_BLOCKS));
+    KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(win_stats) & 7u) == 0, KVZ_EINVAL, "kvz_flash_fwd_window: alignment");
+    KVZ_REQUIRE(q_stride_head % 8 == 0 && q_stride_group % 8 == 0 && q_stride_pos % 8 == 0 && o_stride_head % 4 == 0 &&
+                    o_stride_group % 4 == 0 && o_stride_pos % 4 == 0, KVZ_EINVAL, "kvz_flash_fwd_window: strides");
+    for (int h = 0; h < Hkv; ++h)
+        KVZ_REQUIRE(win_sink >= 0 && win_start >= win_sink && win_end >= win_start && win_end <= k_meta_host[Hkv + h] - q_len, KVZ_EINVAL,
+                    "kvz_flash_fwd_window: bad window sink=%d start=%d end=%d len=%d q_len=%d", win_sink, win_start, win_end,
+                    k_meta_host[Hkv + h], q_len);
+    KVZ_REQUIRE(win_stats_head_stride >= (int64_t)G * q_len, KVZ_EINVAL, "kvz_flash_fwd_window: statistics stride too small");
+    return flash2_fwd(q, q_stride_head, q_stride_group, q_stride_pos, k, v, nullptr, nullptr, 0, k_meta_host, Hkv, G, q_len, scale, 1,
+                      dtype, out, o_stride_head, o_stride_group, o_stride_pos, nullptr, (hipStream_t)stream_, win_sink, win_start, win_end,
+                      win_stats, win_stats_head_stride);
+}

@@ -19,6 +19,8 @@
 // The 16-row kernel stays for what this one does not take: head dim 64, key splits for short row counts (kvz_flash.hip).
 #include "kvz_mfma_lds.h"
 
+#include <math.h>
+
 #include <type_traits>
 
 namespace kvz {
@@ -49,9 +51,16 @@ struct Flash2Args {
     int Hkv, G, q_len, causal;
     float scale;
     int n_rt;                         // row tiles per head
+    // scoring window (f2: the row statistics of KVScore._get_score come out of the forward's own QK^T tiles): keys [0, win_sink) ++
+    // [win_start, win_end) ++ the last q_len keys of the segment; win_stats [Hkv, win_stats_stride] float2 (m_r, l'_r), row index
+    // g*q_len + i (the layout the column-maximum pass reads)
+    int win_sink, win_start, win_end;
+    float2* win_stats;
+    int64_t win_stats_stride;
+    float win_c, win_rcp;             // sqrt(D) and its exact reciprocal (0: divide)
 };
 
-template <typename T>
+template <typename T, bool WIN, bool FAST>
 __global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a) {
     typedef typename Mfma32<T>::v8 v8;
     constexpr int D = 128, ROW_BYTES = D * 2, KK = D / 16, DB = D / 32;
@@ -147,6 +156,10 @@ __global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a)
 #pragma unroll
     for (int db = 0; db < DB; ++db) vx[db] = vaddr0 + (uint32_t)((db ^ rho) << 6);
 
+    // window statistics of this lane's half of the row (attention/score.py:57-61 on the forward's accumulators): reference value
+    // wm (a 16-bit logit), wl = sum of 2^(x*log2e - fl(wm*log2e)) over the window keys seen so far
+    float wm = -INFINITY, wml2 = 0.f, wl = 0.f;
+    const int rep0 = len - a.q_len;   // first key of the repeat chunk
     float m2 = -INFINITY;   // running maximum in the exp2 domain (scaled logits * log2e)
     float l_run = 0.f;
     f16v o[DB];
@@ -185,6 +198,43 @@ __global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if ((i & 3) + 8 * (i >> 2) > rel) s[sb][i] = -INFINITY;
+            }
+        }
+        if constexpr (WIN) {
+            const int t0w = t * F2_KT;
+            const bool hit = t0w < a.win_sink || (t0w < a.win_end && t0w + F2_KT > a.win_start) || t0w + F2_KT > rep0;
+            if (hit) {  // (wave-uniform; 3 % of the tiles of a scoring forward)
+                constexpr float L2E = 1.44269504088896340736f;
+                float x[2][16];
+                float xmax = -INFINITY;
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = t0w + sb * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
+                        const bool in = key < a.win_sink || (key >= a.win_start && key < a.win_end) || key >= rep0;
+                        // (hidden keys of the repeat chunk are already -inf when the tile took the masked path; a window tile that
+                        // reaches into the causal zone always does)
+                        const float xv = round_chain<T, FAST>(s[sb][i], a.win_c, a.win_rcp);
+                        x[sb][i] = (in && key <= limit) ? xv : -INFINITY;
+                        xmax = fmaxf(xmax, x[sb][i]);
+                    }
+                if (xmax > wm) {  // the reference only moves up (per lane: the two halves of a row are merged at the end)
+                    const float nml2 = xmax * L2E;
+                    wl *= (wm == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(wml2 - nml2);
+                    wm = xmax;
+                    wml2 = nml2;
+                }
+                const float nw = (wm == -INFINITY) ? 0.f : -wml2;
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        acc0 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[sb][i], L2E, nw));
+                        acc1 += __builtin_amdgcn_exp2f(__builtin_fmaf(x[sb][i + 1], L2E, nw));
+                    }
+                wl += acc0 + acc1;
             }
         }
         float tmax = s[0][0];
@@ -275,6 +325,15 @@ __global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a)
         }
     }
 
+    if constexpr (WIN) {
+        // merge the two half-waves of a row (disjoint keys), as the row-statistics pass does: (m, l' relative to fl(m*log2e))
+        const float m_o = __shfl_xor(wm, 32, 64), ml2_o = __shfl_xor(wml2, 32, 64), l_o = __shfl_xor(wl, 32, 64);
+        const float M = fmaxf(wm, m_o);
+        const float ML2 = (wm >= m_o) ? wml2 : ml2_o;
+        const float la = (wm == -INFINITY) ? 0.f : wl * __builtin_amdgcn_exp2f(wml2 - ML2);
+        const float lb = (m_o == -INFINITY) ? 0.f : l_o * __builtin_amdgcn_exp2f(ml2_o - ML2);
+        if (rvalid && half == 0) a.win_stats[(int64_t)h * a.win_stats_stride + (int64_t)qg * a.q_len + qi] = make_float2(M, la + lb);
+    }
     // ---- normalise and store: lane holds O^T[d = db*32 + 8*(i>>2) + 4*half + (i&3)][row l31] ----
     l_run += __shfl_xor(l_run, 32, 64);
     if (rvalid) {
@@ -301,9 +360,10 @@ bool flash2_takes(int Hkv, int G, int q_len, int D) {
 
 // (same arguments as kvz_flash_fwd, which dispatches here; no workspace)
 int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k,
-                        const void* v, const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
-                        int Hkv, int G, int q_len, float scale, int causal, int dtype, void* out, int64_t o_stride_head,
-                        int64_t o_stride_group, int64_t o_stride_pos, float* lse_out, hipStream_t stream) {
+               const void* v, const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host,
+               int Hkv, int G, int q_len, float scale, int causal, int dtype, void* out, int64_t o_stride_head,
+               int64_t o_stride_group, int64_t o_stride_pos, float* lse_out, hipStream_t stream, int win_sink, int win_start,
+               int win_end, float* win_stats, int64_t win_stats_head_stride) {
     Flash2Args a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.lse = lse_out;
     a.k_start = k_start; a.k_len = k_len; a.k_len_offset = k_len_offset;
@@ -317,10 +377,21 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
     a.Hkv = Hkv; a.G = G; a.q_len = q_len; a.causal = causal; a.scale = scale;
     const int R = q_len * G;
     a.n_rt = (R + F2_ROWS - 1) / F2_ROWS;
+    a.win_sink = win_sink; a.win_start = win_start; a.win_end = win_end;
+    a.win_stats = reinterpret_cast<float2*>(win_stats); a.win_stats_stride = win_stats_head_stride;
+    a.win_c = sqrtf(128.f);
+    a.win_rcp = win_stats ? score_exact_reciprocal(128, dtype) : 0.f;
     const dim3 grid(a.n_rt, Hkv), block(F2_THREADS);
     ProfScope ps("flash_fwd", stream);
-    if (dtype == KVZ_F16) hipLaunchKernelGGL((flash2_fwd_kernel<_Float16>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((flash2_fwd_kernel<__bf16>), grid, block, 0, stream, a);
+#define KVZ_F2_LAUNCH(T, WIN, FAST) hipLaunchKernelGGL((flash2_fwd_kernel<T, WIN, FAST>), grid, block, 0, stream, a)
+    if (!win_stats) {
+        if (dtype == KVZ_F16) KVZ_F2_LAUNCH(_Float16, false, true); else KVZ_F2_LAUNCH(__bf16, false, true);
+    } else if (a.win_rcp != 0.f) {
+        if (dtype == KVZ_F16) KVZ_F2_LAUNCH(_Float16, true, true); else KVZ_F2_LAUNCH(__bf16, true, true);
+    } else {
+        if (dtype == KVZ_F16) KVZ_F2_LAUNCH(_Float16, true, false); else KVZ_F2_LAUNCH(__bf16, true, false);
+    }
+#undef KVZ_F2_LAUNCH
     KVZ_CHECK_LAUNCH("flash2_fwd_kernel");
     return KVZ_OK;
 }

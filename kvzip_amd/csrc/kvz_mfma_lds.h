@@ -74,4 +74,18 @@ __device__ static inline void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // every tile staged ahead.  LDS traffic of this wave is complete (lgkmcnt 0) before the barrier.
 __device__ static inline void block_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
+// The division is an IEEE fp32 division whose result is immediately rounded to 16 bits.  Because the dividend is a
+// 16-bit value there are only 65536 cases, and the host verifies exhaustively (find_exact_reciprocal) that one
+// fp32 multiply by `rcp` gives the identical 16-bit result for all of them; if no such constant exists the kernel
+// falls back to the true division.
+template <typename T, bool FAST>
+__device__ static inline float round_chain(float acc, float c, float rcp) {
+    const T h1 = (T)acc;
+    const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
+    const T h2 = (T)d;
+    return (float)h2;
+}
+
+
 }  // namespace kvz

@@ -74,6 +74,8 @@ struct ScoreArgs {
     int64_t out_head_stride;
     int row_splits;      // pass B
     int unit_rows;       // rows per unit of the pass-A partition (PA_ROWS)
+    int* unit_nseg;      // [units] partial statistics per unit (written by the pass-A block that finishes the unit, read by pass B)
+    int max_seg;         // most partials any unit has (PaPlan::max_seg)
     int n_kv_heads;
     float c;             // float32(sqrt(D))
     float rcp;           // reciprocal constant r such that half(x*r) == half(x/c) for EVERY 16-bit x (0 = none found)
@@ -81,19 +83,6 @@ struct ScoreArgs {
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
 };
-
-// reference rounding chain (attention/score.py:57): half(matmul) / sqrt(D) -> half.
-// The division is an IEEE fp32 division whose result is immediately rounded to 16 bits.  Because the dividend is a
-// 16-bit value there are only 65536 cases, and the host verifies exhaustively (find_exact_reciprocal) that one
-// fp32 multiply by `rcp` gives the identical 16-bit result for all of them; if no such constant exists the kernel
-// falls back to the true division.
-template <typename T, bool FAST>
-__device__ static inline float round_chain(float acc, float c, float rcp) {
-    const T h1 = (T)acc;
-    const float d = FAST ? (float)h1 * rcp : (float)h1 / c;
-    const T h2 = (T)d;
-    return (float)h2;
-}
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
 // arguments read it through the mixed-precision fma: no separate conversion back to fp32)
@@ -496,6 +485,7 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
 #endif
 
 #if KVZ_TRACE
+__device__ unsigned long long g_trace_b[8 * 8 * 20 * 8];   // pass B: 8 blocks x 8 waves x 20 tiles x 8 stamps (+ slot 19: prologue / epilogue)
 __device__ unsigned long long g_trace2[8 * 8 * 40 * 16];
 #define KVZ_STAMP(i) do { ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1010,6 +1000,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                 asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
             }
         }
+        if (cur.k != u_end && threadIdx.x == 0) {
+            // this block walked the unit to its end: the unit has cur.z + 1 partials (pass B merges exactly that many)
+            int* dst = a.unit_nseg + cur.k;
+            const int val = cur.z + 1;
+            asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+        }
         KVZ_STAMP(9);
         if (!valid(nxt)) break;
         // ---- switch to the next item: fragments of its first two blocks are in registers, its query rows landed before the
@@ -1071,30 +1067,15 @@ __device__ static inline float2 merge_row_stats(const float2* __restrict__ stats
     const float delta = __builtin_fmaf(M, L2E, -ML2);
     return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
-// number of blocks of pass A that touched unit u (= partial statistics per row of the unit)
-__device__ static inline int plan_unit_slices(const PaPlan& plan, int u) {
-    // first block whose range reaches into unit u: the smallest b with (unit[b+1], tile[b+1]) > (u, 0)
-    int lo = 0, hi = plan.nb - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const bool reaches = plan.unit[mid + 1] > u || (plan.unit[mid + 1] == u && plan.tile[mid + 1] > 0);
-        if (reaches) hi = mid;
-        else lo = mid + 1;
-    }
-    int slices = 1;
-    while (lo + slices < plan.nb && plan.unit[lo + slices] == u && plan.tile[lo + slices] > 0) ++slices;
-    return slices;
-}
-
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a, PaPlan plan) {
+__global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     constexpr int RING = 3;  // query-row tile p of the block's slice lives in buffer p % 3 (see score_rowstat2_kernel)
-    constexpr int MAX_UNITS = PB_STAT_TILES * SC_TILE / 32 + 2;  // units (>= 32 rows each) a row slice can reach into
     __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + PB_STAT_TILES * SC_TILE * 8];
-    __shared__ int unit_slices[MAX_UNITS];
+    __shared__ int nan_rows;  // some row of the slice has NaN statistics (inf / NaN in Q or K): the reference's softmax row is NaN and
+                              // amax over the rows propagates it to EVERY key of the head (attention/score.py:59-63)
     float2* const lstat = reinterpret_cast<float2*>(lds + RING * C::TILE_BYTES);
     constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
     typedef std::integral_constant<int, 0> I0;
@@ -1165,31 +1146,67 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
 #pragma unroll
         for (int i = 0; i < 16; ++i) best[g][i] = hold[g][i] = -INFINITY;
 
+#if KVZ_TRACE
+    unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool tracing = (blockIdx.x % 32 == 5) && lane == 0;
+    unsigned long long* tr = g_trace_b + (((blockIdx.x / 32) % 8) * 8 + wave) * (20 * 8);
+    int tp = 0;
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     if (t_begin < t_end) {
         stage(0);
-        if (t_begin + 1 < t_end) stage(1);
-        // ---- merged statistics of the block's row slice -> LDS (the first two tiles are in flight meanwhile) ----
+        // ---- merged statistics of the block's row slice -> LDS (the first tile is in flight meanwhile; the second one is issued
+        // AFTER these loads: the prologue of all 256 blocks is one burst that fills a CU at ~11 B/clk, and the tile loop can start
+        // as soon as the stationary keys, the first tile and the statistics are there - the second tile is awaited at the first
+        // hand-over) ----
         {
+            // two dependent round trips to memory: the unit's partial count, then all of its partials at once
             const int row_lo = t_begin * SC_TILE, nrows = (t_end - t_begin) * SC_TILE;
-            const int u_lo = row_lo / a.unit_rows, u_hi = min(R - 1, row_lo + nrows - 1) / a.unit_rows;
-            for (int uu = threadIdx.x; uu <= u_hi - u_lo; uu += NWAVES * 64)
-                unit_slices[uu] = plan_unit_slices(plan, (u_lo + uu) * a.n_kv_heads + h);
+            if (threadIdx.x == 0) nan_rows = 0;
             __syncthreads();
             const int64_t rows_total = (int64_t)a.n_kv_heads * a.stats_stride;
+            bool bad = false;
+            constexpr int MAXS = 4;  // partials fetched in one go (more: the general loop below)
             for (int idx = threadIdx.x; idx < nrows; idx += NWAVES * 64) {
                 const int r = row_lo + idx;
                 float2 v = make_float2(INFINITY, 0.f);
-                if (r < R) v = merge_row_stats(a.stats, rows_total, (int64_t)h * a.stats_stride + r, unit_slices[r / a.unit_rows - u_lo]);
+                if (r < R) {
+                    const int64_t i = (int64_t)h * a.stats_stride + r;
+                    const int nseg = a.unit_nseg ? a.unit_nseg[(r / a.unit_rows) * a.n_kv_heads + h] : 1;  // (null: statistics already merged)
+                    if (a.max_seg <= MAXS) {
+                        constexpr float L2E = 1.44269504088896340736f;
+                        float2 ps[MAXS];
+#pragma unroll
+                        for (int sgm = 0; sgm < MAXS; ++sgm) ps[sgm] = a.stats[(int64_t)min(sgm, nseg - 1) * rows_total + i];
+                        float M = -INFINITY;
+#pragma unroll
+                        for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nseg) M = fmaxf(M, ps[sgm].x);
+                        const float ML2 = M * L2E;
+                        float Lp = 0.f;
+#pragma unroll
+                        for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nseg) Lp += ps[sgm].y * __builtin_amdgcn_exp2f(ps[sgm].x * L2E - ML2);
+                        const float delta = __builtin_fmaf(M, L2E, -ML2);
+                        v = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
+                    } else {
+                        v = merge_row_stats(a.stats, rows_total, i, nseg);
+                    }
+                    bad |= !(v.x == v.x) || !(v.y == v.y);
+                }
                 lstat[idx] = v;
             }
+            if (bad) atomicOr(&nan_rows, 1);
         }
+
 #pragma unroll
         for (int g = 0; g < PB_RG; ++g)
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) {
                 asm volatile("" : "+v"(ak[g][kk]));  // the wait for the stationary keys belongs here
             }
-        stage_wait();
+        const bool two = t_begin + 1 < t_end;
+        if (two) stage(1);  // (after every compiler-visible load has been waited for: its vmcnt(0) would wait for this tile as well)
+        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // everything but the second tile
+        else stage_wait();
         block_barrier();
         u32x4 fr[2][C::KK];
         load_frags(fr[0], I0{}, I0{});
@@ -1259,25 +1276,43 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             const float2* const ls = lstat + (t - t_begin) * SC_TILE + l31;
 #pragma unroll
             for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = ls[kb * 32];
+            KVZ_STAMP(0);
             step(acc[1], acc[0], fr[1], st[0], std::false_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
+            KVZ_STAMP(1);
             step(acc[0], acc[1], fr[0], st[1], std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+            KVZ_STAMP(2);
             step(acc[1], acc[0], fr[1], st[2], std::false_type{}, [&]() __attribute__((always_inline)) {
                 // hand-over: the tile two positions ahead goes into the buffer the previous hand-over freed, its DMA is issued
                 // BEFORE the barrier; the counted wait leaves exactly those pieces in flight
+                KVZ_STAMP(4);
                 if (t + 2 < t_end) {
                     stage(B2);
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
                 } else {
                     stage_wait();
                 }
+                KVZ_STAMP(5);
                 block_barrier();  // the next tile has landed for everybody, every fragment of this tile has been read
+                KVZ_STAMP(6);
                 if (t + 1 < t_end) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
             });
+            KVZ_STAMP(3);
             // (after the last tile the chain issued here is not used)
             step(acc[0], acc[1], fr[0], st[3], std::true_type{}, [&]() __attribute__((always_inline)) {
                 if (t + 1 < t_end) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
             });
+            KVZ_STAMP(7);
+#if KVZ_TRACE
+            if (tracing && tp < 19) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tr[tp * 8 + i] = ts[i];
+                ++tp;
+            }
+#endif
         };
+#if KVZ_TRACE
+        if (tracing) { tr[19 * 8 + 0] = t_entry; tr[19 * 8 + 1] = __builtin_amdgcn_s_memtime(); }   // entry, start of the tile loop
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) mfma_step(acc[0], fr[0], kk);
@@ -1293,7 +1328,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             if (++t >= t_end) break;
         }
     }
-    // maximum over the 32 query-row lanes of each half-wave; lane 0 / 32 then hold the 16 keys (i&3)+8*(i>>2)+4*half
+    // maximum over the 32 query-row lanes of each half-wave; lanes 16 / 48 then hold the 16 keys (i&3)+8*(i>>2)+4*half
     // (lane id recomputed: values kept alive across the loop for this epilogue would cost registers - one of them spilled)
     const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int l31_e = lane_e & 31, half_e = lane_e >> 5;
@@ -1302,7 +1337,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             // all-reduce inside each row of 16 lanes with DPP (rotate by 8 and 4, then the two quad permutations: four VALU
-            // instructions, no LDS), one cross-row exchange through ds_bpermute
+            // instructions, no LDS), then one cross-row step
             float b = best[g][i];
             auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
@@ -1311,29 +1346,37 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             b = fmaxf(b, dpp(b, std::integral_constant<int, 0x124>{}));  // row_ror:4
             b = fmaxf(b, dpp(b, std::integral_constant<int, 0x4E>{}));   // quad_perm:[2,3,0,1]
             b = fmaxf(b, dpp(b, std::integral_constant<int, 0xB1>{}));   // quad_perm:[1,0,3,2]
-            b = fmaxf(b, __shfl_xor(b, 16, 64));
+            // rows 1 and 3 take in the maximum of the row before them (row_bcast:15, row mask 0b1010; rows 0 and 2 keep theirs): lanes
+            // 16-31 / 48-63 now hold the maximum of their half-wave - no LDS round trip (ds_bpermute) per value
+            b = fmaxf(b, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, b), __builtin_bit_cast(int, b), 0x142, 0xa, 0xf, false)));
             best[g][i] = b;
         }
-        if (l31_e == 0) {
+        const bool poison = (t_begin < t_end) && nan_rows != 0;
+        if (l31_e == 16) {
             if (a.log_out) {
-                // log-softmax values are <= 0 (clamped: rounding may leave +1e-7, and exp of either rounds to the same 16-bit 1.0), and
+                // log-softmax values are <= 0 (rounding may leave +1e-7: clamped, exp of either rounds to the same 16-bit 1.0), and
                 // for non-positive floats "larger" is "smaller bit pattern": the maximum over the row slices is an unsigned minimum
                 uint32_t* dst = a.log_out + (int64_t)h * a.log_head_stride;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int j = j0 + g * 32 + (i & 3) + 8 * (i >> 2) + 4 * half_e;
-                    if (j < a.m) atomicMin(dst + j, __builtin_bit_cast(uint32_t, fminf(best[g][i], 0.f)) | 0u);
+                    // (encoding: NaN -> 0 wins every minimum; a value >= 0 -> 1, the smallest positive pattern, exp of it is 1.0)
+                    const uint32_t enc = poison ? 0u : (best[g][i] >= 0.f ? 1u : __builtin_bit_cast(uint32_t, best[g][i]));
+                    if (j < a.m) atomicMin(dst + j, enc);
                 }
             } else {
                 float* dst = a.colpart + ((int64_t)ysplit * a.n_kv_heads + h) * a.m;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int j = j0 + g * 32 + (i & 3) + 8 * (i >> 2) + 4 * half_e;
-                    if (j < a.m) dst[j] = best[g][i];
+                    if (j < a.m) dst[j] = poison ? __builtin_nanf("") : best[g][i];
                 }
             }
         }
     }
+#if KVZ_TRACE
+    if (tracing) { tr[19 * 8 + 2] = ts[7]; tr[19 * 8 + 3] = __builtin_amdgcn_s_memtime(); }   // end of the last tile, end of the kernel
+#endif
 }
 
 template <typename T>
@@ -1343,8 +1386,13 @@ __global__ void score_finalize_kernel(const float* __restrict__ colpart, int spl
     const int h = blockIdx.y;
     if (j >= m) return;
     float t = -INFINITY;
-    for (int s = 0; s < splits; ++s) t = fmaxf(t, colpart[((int64_t)s * Hkv + h) * m + j]);
-    out[(int64_t)h * out_head_stride + j] = (T)expf(t);
+    bool nan = false;
+    for (int s = 0; s < splits; ++s) {
+        const float v = colpart[((int64_t)s * Hkv + h) * m + j];
+        nan |= !(v == v);  // (fmaxf drops a NaN operand; the reference's amax propagates it)
+        t = fmaxf(t, v);
+    }
+    out[(int64_t)h * out_head_stride + j] = (T)(nan ? __builtin_nanf("") : expf(t));
 }
 
 // log buffer -> scores: entries still holding the fill pattern (-inf: never scored) leave `out` untouched
@@ -1354,7 +1402,7 @@ __global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int6
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t b = log[i];
-    if (b != SC_LOG_EMPTY) out[i] = (T)expf(__builtin_bit_cast(float, b));
+    if (b != SC_LOG_EMPTY) out[i] = (T)(b == 0u ? __builtin_nanf("") : expf(__builtin_bit_cast(float, b)));  // 0 = NaN (see pass B)
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1446,6 +1494,7 @@ static inline float f16_bits_to_f32(uint16_t h) {
 static float find_exact_reciprocal_search(float c, int dtype);
 // memoised per (dtype, D): four fixed slots, each initialised exactly once (callers may come from several host threads:
 // ctypes releases the GIL) - the 5 x 65536-case search runs at most four times per process, never on a later launch path
+float score_exact_reciprocal(int D, int dtype);
 static float find_exact_reciprocal(int D, int dtype) {
     static std::once_flag once[2][2];
     static float value[2][2];
@@ -1453,6 +1502,7 @@ static float find_exact_reciprocal(int D, int dtype) {
     std::call_once(once[ti][di], [&] { value[ti][di] = find_exact_reciprocal_search(sqrtf((float)D), dtype); });
     return value[ti][di];
 }
+float score_exact_reciprocal(int D, int dtype) { return (D == 64 || D == 128) ? find_exact_reciprocal(D, dtype) : 0.f; }
 static float find_exact_reciprocal_search(float c, int dtype) {
     const float base = 1.0f / c;
     float cand[5] = {base, nextafterf(base, 1.f), nextafterf(base, 0.f), 0.f, 0.f};
@@ -1487,16 +1537,19 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         return KVZ_EUNSUPPORTED;
     }
     a.unit_rows = PA_ROWS;
+    a.max_seg = plan.max_seg;
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
-    {
+    if (a.unit_nseg) {  // (null: the row statistics came out of the scoring forward's attention kernel - kvz_flash_fwd_window)
         ProfScope ps("score_rowstat", stream);
         hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
+        KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
+    } else {
+        a.max_seg = 1;
     }
-    KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
     const int ctiles = (a.m + PB_COLS - 1) / PB_COLS;
     {
         ProfScope ps("score_colmax", stream);
-        hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a, plan);
+        hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_colmax3_kernel");
     if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
@@ -1526,16 +1579,19 @@ static inline size_t score_stats_bytes(int Hkv, int G, int q_len, int m, int sin
 static inline size_t score_colpart_bytes(int Hkv, int G, int q_len, int m) {
     return align256((size_t)score_row_splits(Hkv, G, q_len, m) * Hkv * m * sizeof(float));
 }
+static inline size_t score_nseg_bytes(int Hkv, int G, int q_len) {
+    return align256((size_t)((G * q_len + PA_ROWS - 1) / PA_ROWS) * Hkv * sizeof(int));
+}
 
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0 || sink < 0) return 0;
-    return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m);
+    return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len);
 }
 
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_);
+                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0);
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                                int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
@@ -1551,6 +1607,15 @@ extern "C" int kvz_score_chunk_log(const void* q, int64_t q_head_stride, const v
     KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_chunk_log: bad log buffer");
     return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
                             log_head_stride, ws, ws_bytes, stream_);
+}
+
+extern "C" int kvz_score_from_stats_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
+                                       int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, const float* stats,
+                                       int64_t stats_head_stride, uint32_t* log_out, int64_t log_head_stride, kvz_stream_t stream_) {
+    KVZ_REQUIRE(stats && log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_from_stats_log: bad buffers");
+    KVZ_REQUIRE(stats_head_stride < (1ll << 31), KVZ_EUNSUPPORTED, "kvz_score_from_stats_log: statistics stride too large");
+    return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
+                            log_head_stride, nullptr, 0, stream_, stats, stats_head_stride);
 }
 
 extern "C" int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream_) {
@@ -1577,9 +1642,9 @@ extern "C" int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out,
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_) {
+                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride) {
     hipStream_t stream = (hipStream_t)stream_;
-    KVZ_REQUIRE(q && k && (out || log_out) && ws, KVZ_EINVAL, "kvz_score_chunk: null pointer");
+    KVZ_REQUIRE(q && k && (out || log_out) && (ws || merged_stats), KVZ_EINVAL, "kvz_score_chunk: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
     KVZ_REQUIRE(D == 64 || D == 128, KVZ_EUNSUPPORTED, "kvz_score_chunk: head_dim %d unsupported (64 or 128)", D);
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_score_chunk: bad dtype %d", dtype);
@@ -1591,7 +1656,7 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
                 "kvz_score_chunk: head strides must be multiples of 8 elements");
     KVZ_REQUIRE((int64_t)G * q_head_stride * 2 < (1ll << 31) && (int64_t)klen * D * 2 < (1ll << 31), KVZ_EUNSUPPORTED,
                 "kvz_score_chunk: a KV head (and the query heads of its group) must span less than 2 GiB");
-    KVZ_REQUIRE(ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink), KVZ_EWORKSPACE,
+    KVZ_REQUIRE(merged_stats || ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink), KVZ_EWORKSPACE,
                 "kvz_score_chunk: workspace too small");
     ScoreArgs a{};
     a.q = q; a.k = k; a.q_head_stride = q_head_stride; a.k_head_stride = k_head_stride;
@@ -1599,6 +1664,16 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.stats = reinterpret_cast<float2*>(ws);
     a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
+    a.unit_nseg = reinterpret_cast<int*>(reinterpret_cast<char*>(a.colpart) + score_colpart_bytes(Hkv, G, q_len, m));
+    if (merged_stats) {  // pass B only: merged (m_r, l'_r) per row [Hkv, merged_stride], no partials, no workspace
+        KVZ_REQUIRE(log_out, KVZ_EINVAL, "kvz_score_from_stats: the log buffer is the only output of this path");
+        KVZ_REQUIRE(merged_stride >= (int64_t)G * q_len && (reinterpret_cast<uintptr_t>(merged_stats) & 7u) == 0, KVZ_EINVAL,
+                    "kvz_score_from_stats: bad statistics buffer");
+        a.stats = reinterpret_cast<float2*>(const_cast<float*>(merged_stats));
+        a.stats_stride = (int)merged_stride;
+        a.colpart = nullptr;
+        a.unit_nseg = nullptr;
+    }
     a.out = out; a.out_head_stride = out_head_stride;
     a.log_out = log_out; a.log_head_stride = log_head_stride;
     a.dq = make_fastdiv(q_len);
@@ -1654,6 +1729,9 @@ extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtyp
 #if KVZ_TRACE
 extern "C" int kvz_debug_read_trace2(unsigned long long* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace2), bytes);
+}
+extern "C" int kvz_debug_read_trace_b(unsigned long long* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace_b), bytes);
 }
 #endif
 

@@ -71,7 +71,7 @@ class _CacheBase(KVScore):
 
     # -- dense (pre-prune) storage --------------------------------------------------------------
     def _dense_append(self, layer_idx: int, key_states: torch.Tensor, value_states: torch.Tensor):
-        if key_states.device != self.device and key_states.is_cuda:
+        if key_states.is_cuda and key_states.device.index != self.device.index and self.device.index is not None:
             raise ops.KvzError(f"layer {layer_idx} lives on {key_states.device}, the cache on {self.device}: a cache object (its streams, "
                                "events and workspaces) works on ONE device - load the model on one GPU (one context per GPU is the "
                                "multi-GPU scheme, kvzip_amd/dist.py)")

@@ -435,6 +435,35 @@ def flash_fwd(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, causa
     return out
 
 
+def flash_fwd_window(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, sink: int, start: int, end: int,
+                     stats: torch.Tensor, softmax_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+    """The dense causal forward of a scoring pass (``flash_fwd``) that also writes the row statistics of ``KVScore._get_score`` for the
+    window ``sink ++ [start, end) ++ last q_len keys`` into ``stats`` (``[Hkv, stride, 2]`` fp32: (m_r, l'_r), row ``g*q_len + i``)
+    from its own QK^T tiles.  Returns ``[1, q, H, D]``, or None when the 32-row kernel does not take the shape (the caller then
+    scores with the two-pass kernels)."""
+    lib = _lib.load()
+    b, H, q_len, D = query.shape
+    Hkv, klen = key.shape[1], key.shape[2]
+    G = H // Hkv
+    if (b != 1 or D != 128 or query.stride(-1) != 1 or query.stride(1) % 8 or query.stride(2) % 8 or key.stride(-1) != 1
+            or key.stride(2) != D or key.stride(1) % D or value.stride(-1) != 1 or value.stride(2) != D or key.stride(1) != value.stride(1)):
+        return None
+    step = key.stride(1) // D if Hkv > 1 else klen
+    meta = _meta_host([h * step for h in range(Hkv)], [klen] * Hkv, Hkv)
+    if meta is None:
+        return None
+    out = torch.empty(1, q_len, H, D, dtype=query.dtype, device=query.device)
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    rc = lib.kvz_flash_fwd_window(query.data_ptr(), G * query.stride(1), query.stride(1), query.stride(2), key.data_ptr(),
+                                  value.data_ptr(), meta, Hkv, G, q_len, D, float(scale), _dtype_code(query.dtype), out.data_ptr(),
+                                  G * D, D, H * D, int(sink), int(start), int(end), stats.data_ptr(), stats.stride(0) // 2, _stream(query))
+    if rc == -4:  # KVZ_EUNSUPPORTED: not a shape of the 32-row kernel
+        check(0, "kvz_flash_fwd_window")
+        return None
+    check(rc, "kvz_flash_fwd_window")
+    return out
+
+
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
                            softmax_scale=None, causal=False, seqused_k=None):
     """Call-compatible stand-in for the reference's use of ``flash_attn.flash_attn_varlen_func``

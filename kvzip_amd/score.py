@@ -125,6 +125,9 @@ class KVScore:
         self.score_deferred = True     # row slices merged by atomics into a log buffer, ONE finalize launch when the scores are read
         self._score_log: Optional[torch.Tensor] = None   # [L, 1, Hkv, N] int32: bit patterns of the fp32 log-scores (-inf = empty)
         self._log_dirty = False
+        self._dev_idx: Optional[int] = None   # index of the ONE device this object works on (resolved at the first scoring call)
+        self._win_stats: List[Optional[torch.Tensor]] = []  # per layer: row statistics written by the scoring forward (f2)
+        self.fuse_forward_score = False       # set by the forward pass this package owns (kvzip_amd.attn via ModelKVzip.scoring)
 
     # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
     @property
@@ -231,10 +234,14 @@ class KVScore:
         assert bsz == 1 and query_states.stride(3) == 1 and query_states.stride(2) == D
         assert key_states.stride(3) == 1 and key_states.stride(2) == D and key_states.dtype == query_states.dtype
         dev = query_states.device
-        if dev != torch.device(self.device) and torch.device(self.device).index is not None:
+        di = self._dev_idx
+        if di is None:  # (resolved once: the cache object lives on ONE device)
+            d0 = torch.device(self.device)
+            di = self._dev_idx = d0.index if d0.index is not None else dev.index
+        if dev.index != di:
             raise ops.KvzError(f"layer {layer_idx} lives on {dev}, the cache on {self.device}: a cache object (side streams, events, "
                                "workspaces) works on ONE device - load the model on one GPU (one context per GPU is the multi-GPU scheme)")
-        if dev.index != torch.cuda.current_device():
+        if di != torch.cuda.current_device():
             raise ops.KvzError(f"the cache lives on {dev} but cuda:{torch.cuda.current_device()} is current: wrap the forward pass in "
                                f"`with torch.cuda.device({dev.index}):` (the library launches on the current HIP device)")
         need = self._ws_need.get((q_len, m, H))
@@ -301,6 +308,70 @@ class KVScore:
                                            ws.data_ptr(), ws.numel())
         ops.check(rc, "kvz_score_chunk_async")
         self._score_fill[layer_idx] = f + m
+
+    # f2: the scoring forward's attention kernel emits the row statistics itself
+    def _score_forward(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int,
+                       softmax_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+        """Dense causal attention of a scoring forward pass AND the scores of the current chunk from ONE QK^T over the window
+        keys: ``kvz_flash_fwd_window`` (caller's stream) applies the scoring rounding chain to the accumulators of the key tiles of
+        ``sink ++ [start_idx, end_idx) ++ repeat chunk`` and leaves the per-row softmax statistics; the column-maximum pass then
+        runs on a side stream (``kvz_score_from_stats_async_log``).  The reference computes that QK^T twice (attention/attn.py:53-54
+        and :75-89); the two-pass scoring call of ``_get_score`` computes the window's part a second time as well.
+        Returns the attention output ``[1, q, H, D]``, or None when the shape is not one the 32-row kernel takes (head_dim 128,
+        enough rows) or the deferred log buffer is not in use - the caller then goes through ``_get_score`` + the plain forward."""
+        lib = ops._lib.load()
+        m = self.end_idx - self.start_idx
+        f = self._score_fill[layer_idx]
+        if self._score_buf.shape[-1] < f + m:
+            self._ensure_score_capacity(f + m)
+        buf, log = self._score_buf, self._score_log
+        n_tot = buf.shape[-1]
+        bsz, H, q_len, D = query_states.shape
+        Hkv = self.n_heads_kv
+        if (log is None or log.shape[-1] != n_tot or not query_states.is_cuda or D != 128 or bsz != 1
+                or query_states.stride(3) != 1 or query_states.stride(2) != D or key_states.stride(3) != 1 or key_states.stride(2) != D):
+            return None
+        if getattr(self, "_pend_app", None) is not None:
+            self._flush_append()  # the forward reads the rows of the repeat chunk
+        dev = query_states.device
+        R = (H // Hkv) * q_len
+        stride = (R + 127) // 128 * 128
+        while len(self._win_stats) <= layer_idx:
+            self._win_stats.append(None)
+        st = self._win_stats[layer_idx]
+        if st is None or st.shape[1] < stride:
+            # (one buffer per layer: its previous reader is this layer's previous scoring call, which update() has waited for)
+            st = self._win_stats[layer_idx] = torch.empty((Hkv, stride, 2), dtype=torch.float32, device=dev)
+        out = ops.flash_fwd_window(query_states, key_states, value_states, self.sink, self.start_idx, self.end_idx, st,
+                                   softmax_scale=softmax_scale)
+        if out is None:
+            return None
+        if self._async < 0:
+            self._async = lib.kvz_async_create(self.n_layers)
+            if self._async < 0:
+                ops.check(self._async, "kvz_async_create")
+        nstreams = 1 if self._score_exclusive else max(1, int(self.n_score_streams))
+        slot = layer_idx % nstreams if nstreams > 1 else 0
+        cur = ops.raw_stream(dev.index)
+        if nstreams == 1:
+            self._wait_score(finalize=False)
+            side = cur
+        else:
+            if len(self._score_side) < nstreams:
+                self._score_side = _side_streams(dev, nstreams)
+            sst = self._score_side[slot]
+            side = sst.cuda_stream
+            query_states.record_stream(sst)
+            self._pending = True
+        out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
+        rc = lib.kvz_score_from_stats_async_log(self._async, layer_idx, cur, side, query_states.data_ptr(), query_states.stride(1),
+                                                key_states.data_ptr(), key_states.stride(1), key_states.shape[2], self.sink,
+                                                self.start_idx, self.end_idx, q_len, Hkv, H // Hkv, D,
+                                                ops._dtype_code(query_states.dtype), st.data_ptr(), st.stride(0) // 2, out_ptr, n_tot)
+        ops.check(rc, "kvz_score_from_stats_async_log")
+        self._log_dirty = True
+        self._score_fill[layer_idx] = f + m
+        return out
 
     # ------------------------------------------------------------------------------------------
     def _stacked_score(self, score) -> torch.Tensor:

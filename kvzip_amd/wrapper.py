@@ -83,6 +83,11 @@ class ModelKVzip:
         self.config = model.config
         self.config._attn_implementation = "kvzip_hip"  # dense path through kvzip_amd.attn, no HF mask construction
         self.kv_type = kv_type
+        # f2: scoring passes can take the row statistics of the scores from the forward's own attention kernel (one QK^T over the
+        # window instead of two).  Built, parity-tested - and OFF by default: the row-statistics pass is bound by its VALU rounding
+        # chain, not by the matrix cores, so sharing the QK^T saves nothing, and inside the forward that chain sits on the critical
+        # path (+17 % on a 2 026 x 35 k forward, profiles/r3_flash_probe.txt) instead of on a side stream beside the MLP GEMMs
+        self.fuse_forward_score = False
         self.head_score_dir = head_score_dir
         self.cache_kwargs = dict(cache_kwargs or {})
         self.gen_kwargs = {"do_sample": False, "max_new_tokens": max_new_tokens}
@@ -190,6 +195,7 @@ class ModelKVzip:
             kv.init_score()
             if hasattr(kv, "fuse_update_score"):
                 kv.fuse_update_score = True  # the forward pass is kvzip_amd.attn: update() is always followed by _get_score()
+                kv.fuse_forward_score = self.fuse_forward_score  # ... and its attention kernel emits the row statistics (f2)
             start_idx_tmp = kv.start_idx
             kv.end_idx = 0
             for prefill_ids_p, repeat_ids_p in self.self_task(ctx_ids, chunk_size=chunk_size,
@@ -204,6 +210,7 @@ class ModelKVzip:
         kv.get_score = False
         if hasattr(kv, "fuse_update_score"):
             kv.fuse_update_score = False
+            kv.fuse_forward_score = False
 
     # ---- generation (reference model/wrapper.py:251-284) ---------------------------------------------------------
     @torch.inference_mode()
@@ -237,6 +244,8 @@ class ModelKVzip:
         (test.py:22-25: ``torch.stack(kv.score, dim=0).squeeze().amax(-1)``) for context-independent, head-level eviction."""
         from . import ops
         score = kv._stacked_score(kv.score)
+        if not score.is_cuda:  # (host-side scores, e.g. loaded from a file: no kernel needed)
+            return score.reshape(score.shape[0], score.shape[-2], score.shape[-1]).amax(-1)
         return ops.rowmax(score.reshape(score.shape[0], score.shape[-2], score.shape[-1]))
 
     def save_head_score(self, kv, data: str, idx: int, head_score_dir: Optional[str] = None) -> str:

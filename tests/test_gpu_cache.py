@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import kvzip_oracle as orc
 from conftest import from_bits, load_golden, to_bits, ulp_diff
 
 pytestmark = pytest.mark.gpu
@@ -375,3 +376,58 @@ def test_decode_graph_equals_per_layer_hooks(dtype):
     b._grow_slack(200)
     with pytest.raises(ops.KvzError):
         step_graph.replay()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_score_forward_fused_statistics(dtype):
+    """f2: the scoring forward's attention kernel emits the row statistics of the scores from its own QK^T tiles
+    (KVScore._score_forward -> kvz_flash_fwd_window + kvz_score_from_stats_async_log).  The attention output must be bit-identical
+    to the plain forward, the scores must agree with the CPU oracle like the two-pass kernels do, and with the two-pass kernels
+    themselves up to the summation order of the row sums (different tile order: a score moves by one step of its grid at most)."""
+    from kvzip_amd import ops
+    from kvzip_amd.kvcache import EvictCache
+    from conftest import check_score_parity
+    lib = ops._lib.load()
+    H, Hkv, D, sink, N = 28, 4, 128, 32, 1500
+    cfg = types.SimpleNamespace(num_hidden_layers=1, num_attention_heads=H, num_key_value_heads=Hkv)
+    g = torch.Generator().manual_seed(123)
+    K0 = torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)
+    V0 = torch.randn(1, Hkv, sink + N, D, generator=g).to(dtype)
+    chunks = [(sink, sink + 700, 713), (sink + 700, sink + N, 826)]
+    ins = [(torch.randn(1, H, q_len, D, generator=g).to(dtype), torch.randn(1, Hkv, q_len, D, generator=g).to(dtype),
+            torch.randn(1, Hkv, q_len, D, generator=g).to(dtype)) for _, _, q_len in chunks]
+    want = torch.cat([orc.get_score(q, torch.cat([K0, kr], dim=2), sink, st, en) for (st, en, _), (q, kr, _) in zip(chunks, ins)], dim=-1)
+
+    def run(fused):
+        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dtype, verbose=False)
+        kv.update(K0.to(DEV), V0.to(DEV), 0)
+        kv.init_score()
+        kv.fuse_update_score = True
+        outs = []
+        for (st, en, q_len), (q, kr, vr) in zip(chunks, ins):
+            kv.start_idx, kv.end_idx = st, en
+            seen = kv._seen_tokens
+            k_all, v_all = kv.update(kr.to(DEV), vr.to(DEV), 0)
+            qd = q.to(DEV)
+            if fused:
+                o = kv._score_forward(qd, k_all, v_all, 0)
+                assert o is not None
+            else:
+                kv._get_score(qd, k_all, 0)
+                o = ops.flash_fwd(qd, k_all, v_all)
+            outs.append(o.clone())
+            kv.slice(seen)
+        return kv.score[0].cpu(), outs
+
+    prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    try:
+        s_fused, o_fused = run(True)
+        s_two, o_two = run(False)
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
+    for a, b in zip(o_fused, o_two):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "the statistics must not change the attention output"
+    check_score_parity(f"fused_forward/{dtype}", s_fused, want)
+    d = ulp_diff(s_fused, s_two)
+    print(f"fused vs two-pass {dtype}: {float((d == 0).float().mean()):.5f} identical, worst {int(d.max())}")
+    assert (d == 0).float().mean() >= 0.995 and d.max() <= 2

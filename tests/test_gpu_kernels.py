@@ -2,6 +2,7 @@
 CPU oracle on seeded inputs.  Integer / byte work (selection masks, compaction, append, metadata) must be
 BIT-EXACT; floating point work carries the tolerance stated in the test."""
 import math
+import types
 
 import numpy as np
 import pytest
@@ -800,3 +801,35 @@ def test_round_chain_exhaustive(dtype, D):
                             got[bad].tolist(), want[bad].tolist())
         if not force_div:
             assert rcp.value != 0.0, "no exact reciprocal found: kernels would fall back to the slow division"
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+@pytest.mark.parametrize("poison", ["inf", "nan"])
+def test_score_chunk_propagates_nan_like_the_reference(poison, deferred):
+    """An inf / NaN in one query row makes that row's softmax NaN in the reference, and amax over the rows carries it to EVERY ctx key
+    of the KV head (attention/score.py:59-63; torch.amax propagates NaN).  Both output paths of the kernel - per-call finalize and
+    the deferred log buffer with its unsigned-minimum merge - must do the same; the other heads stay finite and equal the oracle."""
+    from kvzip_amd.kvcache import EvictCache
+    H, Hkv, D, sink, N, q_len = 8, 2, 128, 16, 700, 333
+    m = N
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, H, q_len, D, generator=g).half()
+    k = torch.randn(1, Hkv, sink + N + q_len, D, generator=g).half()
+    q[0, 1, 200, 5] = float("inf") if poison == "inf" else float("nan")   # query head 1 -> KV head 0
+    want = orc.get_score(q, k, sink, sink, sink + m)
+    assert torch.isnan(want[0, 0].float()).all() and not torch.isnan(want[0, 1].float()).any()
+    if deferred:
+        cfg = types.SimpleNamespace(num_hidden_layers=1, num_attention_heads=H, num_key_value_heads=Hkv)
+        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=torch.float16, verbose=False)
+        kv.update(k[:, :, :sink + N].to(DEV), k[:, :, :sink + N].to(DEV), 0)
+        kv.init_score()
+        assert kv.score_deferred
+        k_all, _ = kv.update(k[:, :, sink + N:].to(DEV), k[:, :, sink + N:].to(DEV), 0)
+        kv._get_score(q.to(DEV), k_all, 0)
+        got = kv.score[0].cpu()
+    else:
+        got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, sink, sink + m).cpu()
+    assert torch.isnan(got[0, 0].float()).all(), "NaN of the poisoned head was dropped"
+    assert not torch.isnan(got[0, 1].float()).any()
+    d = ulp_diff(got[0, 1], want[0, 1])
+    assert (d <= 1).float().mean() >= 0.99 and d.max() <= 16

@@ -39,7 +39,7 @@ def build_model(layers, dtype, dev, vocab=152064):
     return model.eval()
 
 
-def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, ratio=0.3, verbose=True):
+def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, ratio=0.3, verbose=True, fuse_forward=False):
     from kvzip_amd import _lib
     from kvzip_amd.wrapper import ModelKVzip
     lib = _lib.load()
@@ -55,12 +55,13 @@ def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, r
     rep = (torch.randint(0, V, (1, 13), generator=g), torch.randint(0, V, (1, 26), generator=g))
     ctx = torch.randint(0, V, (1, ctx_len), generator=g)
     query = torch.randint(0, V, (1, 24), generator=g)
-    out = {"config": f"Qwen2 random-init L{layers} H28 Hkv4 D128 hidden 3584 bf16, ctx {ctx_len}, ratio {ratio}", "build_s": round(t_build, 2)}
+    out = {"statistics_from_the_forward_kernel": fuse_forward, "config": f"Qwen2 random-init L{layers} H28 Hkv4 D128 hidden 3584 bf16, ctx {ctx_len}, ratio {ratio}", "build_s": round(t_build, 2)}
     gens, scores, logits = {}, {}, {}
     for kv_type in ("evict", "retain"):
         m = ModelKVzip(model, kv_type=kv_type, name="Qwen2.5-7B-random", max_new_tokens=max_new_tokens,
                        cache_kwargs=dict(verbose=False))
         m.set_prompt_ids(sys_ids, post_ids)
+        m.fuse_forward_score = fuse_forward
         torch.cuda.synchronize(); t0 = time.perf_counter()
         kv = m.prefill(ctx, prefill_chunk_size=16000, do_score=False)      # model/wrapper.py:169-195
         torch.cuda.synchronize(); t_prefill = time.perf_counter() - t0
@@ -79,18 +80,42 @@ def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, r
                     captured.update(q=q.cpu().clone(), k=k.cpu().clone(), layer=layer_idx, st=kv.start_idx, en=kv.end_idx, sink=kv.sink)
                 return r
             kv._get_score = spy
-        lib.kvz_prof_reset(); lib.kvz_prof_enable(1)
+            orig_fwd = kv._score_forward
+
+            def spy_fwd(q, k, v, layer_idx, softmax_scale=None):   # (f2: the forward's attention kernel emits the statistics)
+                if kv.start_idx != seen["last_start"]:
+                    seen["chunk"] += 1
+                    seen["last_start"] = kv.start_idx
+                r = orig_fwd(q, k, v, layer_idx, softmax_scale=softmax_scale)
+                if r is not None and (layer_idx, seen["chunk"]) == want_call:
+                    captured.update(q=q.cpu().clone(), k=k.cpu().clone(), layer=layer_idx, st=kv.start_idx, en=kv.end_idx, sink=kv.sink,
+                                    fused_forward=True)
+                return r
+            kv._score_forward = spy_fwd
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.scoring(kv, ctx, repeat_prompt_ids=rep)                             # model/wrapper.py:223-249
         torch.cuda.synchronize(); t_scoring = time.perf_counter() - t0
-        lib.kvz_prof_enable(0)
-        import ctypes as C
-        kern = {}
-        for name in ("score_rowstat", "score_colmax", "flash_fwd"):
-            t, c = C.c_double(0), C.c_int64(0)
-            lib.kvz_prof_read(name.encode(), C.byref(t), C.byref(c))
-            kern[name] = {"total_ms": round(t.value, 2), "launches": int(c.value)}
         scores[kv_type] = torch.stack([s.clone() for s in kv.score], 0)
+        t_forward = None
+        if kv_type == "evict":
+            # the same scoring pass with the scoring kernels switched off: what the repeat-prompt forward passes cost on their own
+            real_get_score = kv._get_score
+            kv.get_score = True
+            saved = (kv._score_buf, kv._score_log, list(kv._score_fill), kv._log_dirty)
+            kv._get_score = lambda q, k, layer_idx: None
+            kv._score_forward = lambda q, k, v, layer_idx, softmax_scale=None: None   # (falls back to the no-op _get_score + plain forward)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            start_tmp = kv.start_idx
+            kv.end_idx = 0
+            for prefill_ids_p, repeat_ids_p in m.self_task(ctx, repeat_prompt_ids=rep):
+                kv.end_idx = kv.start_idx + prefill_ids_p.shape[1]
+                m(repeat_ids_p, kv, update_cache=False)
+                kv.start_idx = kv.end_idx
+            kv.start_idx = start_tmp
+            torch.cuda.synchronize(); t_forward = time.perf_counter() - t0
+            kv._get_score, kv.get_score = real_get_score, False
+            kv._score_forward = orig_fwd if (kv_type == "evict" and oracle) else type(kv)._score_forward.__get__(kv)
+            kv._score_buf, kv._score_log, kv._score_fill, kv._log_dirty = saved[0], saved[1], saved[2], saved[3]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         thres, r_real = kv.prune(ratio)
         torch.cuda.synchronize(); t_prune = time.perf_counter() - t0
@@ -101,8 +126,9 @@ def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, r
         logits[kv_type] = m(q_ids, kv, return_logits=True).logits[0, -1].float().cpu()
         out[kv_type] = {"prefill_s": round(t_prefill, 3), "scoring_s": round(t_scoring, 3), "prune_s": round(t_prune, 4),
                         "generate_s": round(t_gen, 3), "new_tokens": int(gens[kv_type].shape[1]) + 1, "thres": thres, "real_ratio": r_real,
-                        "kv_gb_after_prune": kv._mem(), "scoring_kernels_bracketed": kern,
-                        "note": "scoring_kernels_bracketed: library hipEvent brackets (they serialise the side streams' overlap a little)"}
+                        "kv_gb_after_prune": kv._mem(), "scoring_forward_only_s": round(t_forward, 3) if t_forward else None,
+                        "note": "scoring_s = repeat-prompt forward passes WITH the scoring kernels on the side streams; "
+                                "scoring_forward_only_s = the same passes with _get_score switched off (evict run only)"}
         if captured:
             import kvzip_oracle as orc
             t0 = time.perf_counter()
@@ -115,7 +141,8 @@ def run(ctx_len=32768, layers=28, dev="cuda:0", oracle=True, max_new_tokens=8, r
             d = (key(a) - key(b)).abs()
             out["sampled_call_vs_oracle"] = {"layer": captured["layer"], "window": [captured["st"], captured["en"]], "q_len": captured["q"].shape[2],
                                              "bit_identical": float((d == 0).float().mean()), "within_one_half_ulp": float((d <= 1).float().mean()),
-                                             "worst_half_ulps": int(d.max()), "oracle_s": round(time.perf_counter() - t0, 1)}
+                                             "worst_half_ulps": int(d.max()), "oracle_s": round(time.perf_counter() - t0, 1),
+                                             "statistics_from_the_forward_kernel": bool(captured.get("fused_forward"))}
         del kv, m
     out["evict_equals_retain_tokens"] = bool(torch.equal(gens["evict"], gens["retain"]))
     out["evict_equals_retain_scores"] = bool(torch.equal(scores["evict"], scores["retain"]))
@@ -133,8 +160,9 @@ if __name__ == "__main__":
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--fused-forward", action="store_true", help="f2: row statistics of the scores from the forward's attention kernel")
     a = ap.parse_args()
-    res = run(a.ctx, a.layers, oracle=not a.no_oracle)
+    res = run(a.ctx, a.layers, oracle=not a.no_oracle, fuse_forward=a.fused_forward)
     if a.json:
         with open(a.json, "w") as f:
             json.dump(res, f, indent=1)

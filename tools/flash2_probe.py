@@ -44,3 +44,21 @@ for dt in (torch.float16, torch.bfloat16):
             us2 = timeit(sdpa, n=3)
             line += f" | SDPA {us2:9.1f} us = {fl / us2 / 1e6:6.1f} TFLOP/s, max |flash2 - SDPA| {float((res['flash2'][1] - sdpa().transpose(1, 2)[0].float()).abs().max()):.2e}"
         print(line, flush=True)
+
+# ---- f2: the same forward with the scoring window's statistics switched on (kvz_flash_fwd_window) ----
+print("--- forward with / without the window statistics (sink 32, chunk of 2000 keys, repeat chunk = the query rows)", flush=True)
+prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+try:
+    for dt in (torch.float16, torch.bfloat16):
+        for (H, Hkv, q_len, klen) in ((28, 4, 2026, 35000), (28, 4, 2026, 133000)):
+            D = 128
+            q = torch.randn(1, H, q_len, D, generator=g, device=dev).to(dt)
+            k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt); v = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
+            stats = torch.empty(Hkv, (H // Hkv * q_len + 127) // 128 * 128, 2, dtype=torch.float32, device=dev)
+            start = 32 + 10000
+            us0 = timeit(lambda: ops.flash_fwd(q, k, v))
+            us1 = timeit(lambda: ops.flash_fwd_window(q, k, v, 32, start, start + 2000, stats))
+            same = torch.equal(ops.flash_fwd(q, k, v), ops.flash_fwd_window(q, k, v, 32, start, start + 2000, stats))
+            print(f"{str(dt)[6:]:8s} q {q_len} k {klen}: plain {us0:8.1f} us | with statistics {us1:8.1f} us (+{(us1 / us0 - 1) * 100:.1f} %) | outputs identical: {same}", flush=True)
+finally:
+    lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)

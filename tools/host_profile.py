@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Pure host cost of one (update, _get_score) pair: tiny geometry (the kernels take a few us, the queue never fills), cProfile of
-the Python path.  python tools/host_profile.py [n_streams]"""
+the Python path.  python tools/host_profile.py [n_streams] [unfused]"""
 import cProfile, os, pstats, sys, time, types
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +18,7 @@ Q = torch.randn(L, 1, H, q_len, D, generator=g, device=dev).half()
 K = torch.randn(L, 1, Hkv, q_len, D, generator=g, device=dev).half()
 kv = EvictCache(cfg, (sink, sink + N), device=dev, dtype=torch.float16, verbose=False)
 kv.n_score_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+kv.fuse_update_score = not (len(sys.argv) > 2 and sys.argv[2] == "unfused")   # update + _get_score = one library call
 kv.adopt_dense(store_k, store_v, sink + N)
 kv.init_score()
 chunks = [(sink + c * m, sink + (c + 1) * m) for c in range(N // m)]
