@@ -297,8 +297,12 @@ def main(argv=None):
     n_prof = max(0, args.prof_calls)
     timing = {"on": False}
 
+    prev_kv = [None]
+
     def one_step():
-        kv = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
+        if prev_kv[0] is not None:
+            prev_kv[0].close()   # (the previous step's cache: its events go back now, not when the collector gets to it)
+        kv = prev_kv[0] = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
         kv.n_score_streams = max(1, args.score_streams)
         kv.fuse_update_score = not args.unfused_update  # what kvzip_amd.attn / ModelKVzip.scoring do: update + _get_score = one call
         kv.adopt_dense(store_k, store_v, sink + N)

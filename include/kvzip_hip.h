@@ -82,7 +82,8 @@ int kvz_score_chunk(const void* q, int64_t q_head_stride,
  *   record(ready[slot], caller); wait(side, ready[slot]); kvz_score_chunk(..., side); record(done[slot], side)
  * and kvz_async_wait(handle, slot, stream) orders `stream` behind the scoring calls still pending in `slot` (slot < 0: all).
  * A context is a set of host-side events (no device memory); slots are the caller's (typically one per layer).
- * side == caller degenerates to kvz_score_chunk on that stream. */
+ * side == caller degenerates to kvz_score_chunk on that stream.  A handle is driven from ONE host thread at a time (the per-slot
+ * state is not locked; creation / destruction of handles is thread-safe). */
 int kvz_async_create(int n_slots);   /* -> handle >= 0, or a negative KVZ_E* code */
 int kvz_async_destroy(int handle);
 int kvz_async_wait(int handle, int slot, kvz_stream_t stream);

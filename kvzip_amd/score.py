@@ -174,6 +174,15 @@ class KVScore:
         ops.check(ops._lib.load().kvz_score_log_fill(log.data_ptr(), log.numel(), ops._stream(log)), "kvz_score_log_fill")
         return log
 
+    def close(self):
+        """Release the library-side objects of this cache (the asynchronous-scoring context: 2 events per layer) now instead of at
+        garbage collection.  Waits for outstanding scoring calls first; the object stays usable (a new context is created on demand).
+        A context handle is meant to be driven from ONE host thread (the library does not lock around its per-slot state)."""
+        try:
+            self._wait_score(finalize=False)
+        finally:
+            self._release_async()
+
     def _release_async(self):
         if self._async >= 0:
             try:

@@ -49,6 +49,18 @@ elif what == "attn":
         ops.varlen_attn(q, k, v, starts, lens, 1, 39900, workspace=ws)
     torch.cuda.synchronize()
     print(f"varlen_attn: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
+elif what == "flash":
+    # the scoring forward's dense attention: 2 026 query positions x 28 heads against 133 k keys (kvz_flash2.hip)
+    q = torch.randn(1, H, q_len, D, generator=g, device=dev).to(dt)
+    k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
+    v = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
+    ops.flash_fwd(q, k, v)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ops.flash_fwd(q, k, v)
+    torch.cuda.synchronize()
+    print(f"flash_fwd: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
 elif what == "compact":
     L = 28
     store_k = [torch.randn(1, Hkv, sink + N, D, generator=g, device=dev).to(dt) for _ in range(L)]
