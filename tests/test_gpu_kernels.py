@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import kvzip_oracle as orc
-from conftest import ROOT, check_score_parity, from_bits, load_golden, to_bits, ulp_diff
+from conftest import ROOT, check_attn, check_score_parity, from_bits, load_golden, to_bits, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -545,7 +545,7 @@ def test_varlen_attn_golden(name):
     want = from_bits(G7[name + "/out"], bf).float()
     got = ops().varlen_attn(q, k, v, ks, kl, q_len, int(kl.max()), causal=True).cpu().float()
     tol = 1e-3 if not bf else 8e-3  # bf16 output spacing is 2^-8 relative
-    assert (got - want).abs().max() <= tol, float((got - want).abs().max())
+    check_attn(f"varlen_attn_golden/{name}", got, want, tol)
 
 
 @pytest.mark.parametrize("q_len", [1, 5])
@@ -591,7 +591,7 @@ def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
         q = torch.randn(Hkv, G, D, generator=g, device=DEV).to(dtype)
         want = orc.varlen_attn(q.cpu(), k.cpu(), v.cpu(), starts, lens, 1).float()
         a = ops.varlen_attn(q, k, v, ks, kl, 1, max(lens), workspace=ws, meta_host=meta if it % 2 == 0 else None)
-        assert (a.cpu().float() - want).abs().max() <= tol, it
+        check_attn(f"varlen_attn_ragged_items_and_workspace_reuse/{dtype}/item{it}", a, want, tol)
         assert torch.equal(a[4].cpu().float(), torch.zeros(G, D))  # the empty head: zeros, like flash-attn
     # fused append on the same workspace: one new token per head, then the same answer as append + attention
     kn = torch.randn(1, Hkv, 1, D, generator=g, device=DEV).to(dtype)
@@ -604,7 +604,7 @@ def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
     assert torch.equal(got, ref) and torch.equal(k, k2) and torch.equal(v, v2)
     lens1 = [n + 1 for n in lens]
     want = orc.varlen_attn(q.cpu(), k2.cpu(), v2.cpu(), starts, lens1, 1).float()
-    assert (got.cpu().float() - want).abs().max() <= tol
+    check_attn(f"varlen_attn_ragged_items_and_workspace_reuse/{dtype}", got, want, tol)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -632,7 +632,7 @@ def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
     tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
     for meta in (None, ops._meta_host(starts, lens, Hkv)):
         got = ops.varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), ks, kl, q_len, max(lens), meta_host=meta).cpu().float()
-        assert ((got - want).abs() <= tol + rel * want.abs()).all(), float((got - want).abs().max())
+        check_attn(f"varlen_attn_many_query_rows_vs_oracle/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, rel)
     # the decode kernel (16-row tiles, split keys) must agree with the multi-row kernel on the same call
     if q_len == 64:
         lib = ops._lib.load()
@@ -674,7 +674,7 @@ def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
     s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
     want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
     tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)  # + one output ulp, as above
-    assert ((out[0].float() - want).abs() <= tol + rel * want.abs()).all(), float((out[0].float() - want).abs().max())
+    check_attn(f"flash_fwd_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, rel)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     # the attention hook of the model forward goes through the same kernel
     from kvzip_amd.attn import dense_causal_attention
@@ -717,7 +717,7 @@ def test_flash2_dense_vs_fp32_reference(shape, dtype):
     tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
     err = (out[0].float() - want).abs()
     print(f"\nflash2 {shape} {dtype}: max |err| {float(err.max()):.2e} (16-row kernel: {float((old[0].float() - want).abs().max()):.2e})")
-    assert (err <= tol + rel * want.abs()).all(), float(err.max())
+    check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, rel)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     assert ((out.float() - old.float()).abs() <= 2 * (tol + rel * want.abs().unsqueeze(0))).all()
 
