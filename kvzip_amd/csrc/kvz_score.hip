@@ -18,8 +18,10 @@
 // (reduction over keys = over registers, lane-local); pass B streams query rows and keeps 16 running
 // per-key maxima per lane that are reduced across lanes once at the end.  LDS tiles are XOR-swizzled on
 // 16-byte chunks so that ds_read_b128 fragment reads are bank-conflict free.
-// Bound: SIMD issue - the matrix pipe and the VALU rounding chain share one in-order issue port and barely overlap
-// (profiles/r1_score_timeline.txt).
+// Launches per (layer, chunk): pass A, pass B (which merges pass A's partial statistics in its prologue); the deferred path
+// turns the log buffer of a whole context into 16-bit scores with ONE finalize launch when the scores are read.
+// Bound: SIMD issue - the VALU rounding chain (24 cycles per logit) and the matrix pipe share the issue port of a SIMD
+// (timelines and counters: profiles/r3_passA_timeline.txt, r3_passB_timeline.txt, r3_pmc_traffic.json).
 #include "kvz_common.h"
 #include "kvz_mfma_lds.h"
 
@@ -187,17 +189,17 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 // is exp2(fma(x, log2e, -ml2)) (one rounding), and the common factor 2^(m*log2e - ml2) that this introduces
 // into l is removed exactly at the end (delta = fma(m, log2e, -ml2)).
 //
-// Execution shape (from in-kernel s_memtime traces, per-block Gantt charts and ablations, tools/ablate_score.py):
+// Execution shape (from in-kernel s_memtime traces, per-block Gantt charts and ablations: DESIGN.md 3.1, profiles/r*_timeline.txt):
 //  * one 8-wave block per CU (two waves per SIMD), 32 query rows per wave, 256 rows per key tile: half the L2->LDS
-//    traffic per logit of a 128-row block.  (KVZ_PA_WAVES=4 / KVZ_PA_RG=2 builds the one-wave-per-SIMD variant with two
-//    interleaved matrix chains per wave; a lone wave exposes every latency and is 35 % slower.)
+//    traffic per logit of a 128-row block.  (KVZ_PA_WAVES=4 / KVZ_PA_RG=2 builds the one-wave-per-SIMD variant with 64 rows per
+//    wave: measured 27 % slower in round 3 even with the query rows in the accumulator file - a lone wave cannot fill its own
+//    dependency stalls, profiles/r3_ab_one_wave_per_simd.txt.)
 //  * No global load with a register destination inside the kernel: key tiles AND the query rows of the next item come
 //    in by LDS-DMA issued from assembly.  A load the compiler knows about makes it place s_waitcnt vmcnt(n) wherever
 //    one of the affected registers is touched, and because the hardware counter also holds the DMA, every such wait
 //    drains the tiles staged ahead.  For the same reason the barrier is a bare s_barrier (no fence) and the work
-//    list is STATIC (no atomic queue): block b takes items b, 2G-1-b, 2G+b, ... of a heaviest-first order, which
-//    also removes the 27 % that one-block-per-item launches lost to packing (3.5 rounds of 24-us blocks, the heavy
-//    ones draining alone at the end) and the 2-4 us every block waited for its first tile.
+//    list is STATIC (no atomic queue): an exactly balanced partition of the (row tile, head, key tile) space, cut on the host
+//    (PaPlan below) - one-block-per-item launches lost 27 % to packing and 2-4 us per block waiting for the first tile.
 //  * Latencies are hidden by distance: the DMA of tile p+2 is issued when tile p is handed back, fragment reads run
 //    one 32-key block ahead into a second register set (a prefetch into the registers the chain in flight still
 //    reads stalls the in-order issue), and the hand-over barrier sits right after the LAST matrix chain of a tile
@@ -212,9 +214,8 @@ constexpr int PA_WAVES = KVZ_PA_WAVES;
 constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
 
-// ---- pass A, software-pipelined form (round 2) ------------------------------------------------------------------------
-// Same tiling, staging, static schedule and hand-over protocol as score_rowstat_kernel; what changes is the instruction
-// stream of a wave.  The matrix chain of 32-key block b+1 is issued INSIDE the epilogue of block b, one MFMA per group of
+// ---- the instruction stream of a wave (round 2: software pipeline inside the wave) --------------------------------------
+// The matrix chain of 32-key block b+1 is issued INSIDE the epilogue of block b, one MFMA per group of
 // ~9-18 VALU instructions (groups are pinned with sched_barrier): a wave no longer alternates 256 cycles of matrix pipe
 // with ~500 cycles of VALU, it keeps both busy, and its partner on the SIMD fills the dependency stalls of the chain.
 // The epilogue itself is cut from ~136 to ~80 VALU instructions per 32x32 block:

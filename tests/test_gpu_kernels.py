@@ -609,6 +609,37 @@ def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("q_len", [64, 257])
+def test_varlen_attn_many_query_rows_ragged_on_the_32_row_kernel(q_len, dtype):
+    """The same ragged first-generation-step call forced onto the 32-row kernel (kvz_flash2.hip; it takes such calls by itself once
+    there are >= 128 row blocks, i.e. for long queries): head segments of 4 k / 33 / 1.5 k / 0 context keys + the query's own,
+    by-value and device-array metadata."""
+    from kvzip_amd import ops
+    lib = ops._lib.load()
+    Hkv, G, D = 4, 7, 128
+    lens = [4097 + q_len, 33 + q_len, 1500 + q_len, q_len]
+    g = torch.Generator().manual_seed(q_len + 5)
+    starts, tot = [], 0
+    for ln in lens:
+        starts.append(tot)
+        tot += ln + 5
+    q = torch.randn(Hkv * q_len, G, D, generator=g).to(dtype)
+    k = torch.randn(tot, D, generator=g).to(dtype)
+    v = torch.randn(tot, D, generator=g).to(dtype)
+    want = orc.varlen_attn(q, k, v, starts, lens, q_len).float()
+    ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    try:
+        for meta in (None, ops._meta_host(starts, lens, Hkv)):
+            got = ops.varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), ks, kl, q_len, max(lens), meta_host=meta).cpu().float()
+            check_attn(f"varlen_attn_ragged_flash2/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, rel)
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("q_len", [64, 257])
 def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
     """First generation step on a pruned cache (q_len = len(query) > 1, reference model/wrapper.py:271-274): kvz_varlen_attn
     hands q_len*G > 64 rows to the multi-row kernel (one pass over the keys per 128-row block).  Ragged heads incl. one that
