@@ -65,6 +65,13 @@ def parse(argv=None):
                          "bracketed by hipEvents (kernel durations for the roofline; the GPU is idle at a step's start, nothing is "
                          "drained); all other calls overlap on the side streams")
     ap.add_argument("--unfused-update", action="store_true", help="update and _get_score as two library calls")
+    ap.add_argument("--append", default="kernel", choices=["kernel", "stream"],
+                    help="where the repeat chunk's K,V reach the dense cache in a fused update + _get_score call: 'kernel' = the scoring "
+                         "kernels copy them (no append launch; this driver never reads them back from the cache), 'stream' = a "
+                         "kvz_dense_append launch on the caller's stream (what ModelKVzip.scoring does: its forward reads the rows)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the RCCL process group even with one GPU and push the result gather and the max-over-ranks "
+                         "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
     ap.add_argument("--score-streams", type=int, default=3,
                     help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
     args = ap.parse_args(argv)
@@ -80,16 +87,19 @@ def parse(argv=None):
 class Ranks:
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run or our own spawn)."""
 
-    def __init__(self, expected_world: int, backend: str = "nccl", device=None):
+    def __init__(self, expected_world: int, backend: str = "nccl", device=None, force: bool = False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != expected_world:
             raise SystemExit(f"--gpus {expected_world} but WORLD_SIZE={self.world}")
         self.dist = None
-        if self.world > 1:
+        self.forced = bool(force) and self.world == 1
+        if self.world > 1 or self.forced:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.forced:
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
             kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
@@ -110,7 +120,7 @@ class Ranks:
     def gather_records(self, thres: float, r_real: float, len_k: torch.Tensor, layers: int, Hkv: int):
         """The only exchange the path has: one fixed-size record per context (= per rank), library gather."""
         from kvzip_amd.dist import gather_results, pack_record
-        return gather_results([pack_record(thres, r_real, len_k)], self.world, layers, Hkv)
+        return gather_results([pack_record(thres, r_real, len_k)], self.world, layers, Hkv, force_collective=self.forced)
 
     def close(self):
         if self.dist is not None:
@@ -241,10 +251,11 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ranks = Ranks(args.gpus, "nccl", dev)
+    ranks = Ranks(args.gpus, "nccl", dev, force=args.force_dist)
     rank, world = ranks.rank, ranks.world
 
     from kvzip_amd import _lib, ops
+    from kvzip_amd.dist import backend_version
     from kvzip_amd.kvcache import EvictCache
     lib = _lib.load()
 
@@ -304,7 +315,9 @@ def main(argv=None):
             prev_kv[0].close()   # (the previous step's cache: its events go back now, not when the collector gets to it)
         kv = prev_kv[0] = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
         kv.n_score_streams = max(1, args.score_streams)
-        kv.fuse_update_score = not args.unfused_update  # what kvzip_amd.attn / ModelKVzip.scoring do: update + _get_score = one call
+        # update + _get_score = ONE library call (what kvzip_amd.attn / ModelKVzip.scoring do); this driver owns the repeat pass's
+        # K,V and never reads them back from the cache, so by default the scoring kernels do the append themselves ("kernel")
+        kv.fuse_update_score = False if args.unfused_update else ("kernel" if args.append == "kernel" else True)
         kv.adopt_dense(store_k, store_v, sink + N)
         if head_level:
             # what ModelKVzip.scoring(load_score=True) leaves behind: a stride-0 view of the [L,Hkv] head scores
@@ -545,13 +558,16 @@ def main(argv=None):
             "ratio": ratio, "real_ratio": r_real, "threshold": thres, "kept_rows": int(kept_rows),
             "head_len_min_max": [int(min(lens)), int(max(lens))],
             "parallelism": f"1 context per GPU x{world}, no data-path collective; result records gathered by "
-                           "kvzip_amd.dist.gather_results inside the timed region",
+                           "kvzip_amd.dist.gather_results inside the timed region"
+                           + (f" ({backend_version()}; process group of {world} rank(s)" + (", forced on one GPU)" if ranks.forced else ")")
+                              if ranks.dist is not None else " (no process group: single rank)"),
             "gathered_contexts": len(records),
             "score_streams": max(1, args.score_streams),
             "score_streams_distinct": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
             "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,
             "update_score_fused": not args.unfused_update,
+            "append": "two calls" if args.unfused_update else args.append,
         },
         "roofline": roofline,
         "roofline_stages": stages,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KVZ_ABI_VERSION 3
+#define KVZ_ABI_VERSION 4
 
 /* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
 #define KVZ_F16 0
@@ -122,17 +122,24 @@ int kvz_score_from_stats_async_log(int handle, int slot, kvz_stream_t caller, kv
 int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream);
 int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream);
 
-/* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78,
- * kvz_dense_append on the CALLER's stream, where the forward's own attention reads the rows next) followed by kvz_score_chunk_async_log
- * on the side stream with k = k_cache, klen = fill + t.  Before the append the caller's stream is ordered behind the previous scoring
- * call of the same slot (it read the rows that are about to be overwritten).  Arguments as in the two calls it replaces. */
+/* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78)
+ * followed by kvz_score_chunk_async_log on the side stream with k = k_cache, klen = fill + t.
+ *   append_in_kernel = 0: kvz_dense_append on the CALLER's stream, where the forward's own attention reads the rows next.  Before the
+ *     append the caller's stream is ordered behind the previous scoring call of the same slot (it read the rows that are about to be
+ *     overwritten).
+ *   append_in_kernel = 1 (taken when t == q_len and the rows of k_state are contiguous, ks_row_stride == D; otherwise as 0): NO append
+ *     launch - the row-statistics pass stages the repeat chunk's K rows straight from k_state and its blocks copy them, and the V rows,
+ *     into rows fill .. fill + t of the caches after their last tile.  The rows are then written on the SIDE stream: for callers whose
+ *     stream does not read them back from the cache (a scoring driver that owns the repeat pass's Q/K/V, bench.py); a later reader
+ *     orders itself behind the slot with kvz_async_wait.  Bit-identical scores and cache contents.
+ * Arguments as in the two calls it replaces. */
 int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
                                void* k_cache, void* v_cache, int64_t cache_head_stride, int fill,
                                const void* k_state, const void* v_state,
                                int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride, int64_t vs_row_stride, int t,
                                const void* q, int64_t q_head_stride, int sink, int start, int end, int q_len,
                                int Hkv, int G, int D, int dtype,
-                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
+                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, int append_in_kernel);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

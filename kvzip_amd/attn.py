@@ -16,7 +16,6 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 
 
 def dense_causal_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
@@ -25,32 +24,23 @@ def dense_causal_attention(module, query, key, value, attention_mask=None, dropo
     (query i sees keys j <= i + k - q), like flash-attn's dense kernel used by the reference (attention/attn.py:75-89).
     Device tensors run on the library's own kernels (``kvz_flash_fwd``) straight off the dense cache views - and ONLY there: what
     those kernels do not take (fp32, head dims other than 64 / 128, batch > 1, sliding-window layers, dropout) raises instead of
-    silently falling back to a generic implementation.  CPU tensors (host-logic tests, no GPU) go through torch SDPA."""
-    q_len, k_len = query.shape[-2], key.shape[-2]
-    G = query.shape[1] // key.shape[1]
+    silently falling back to a generic implementation; CPU tensors raise as well."""
+    k_len = key.shape[-2]
     window = kwargs.get("sliding_window", None) or getattr(module, "sliding_window", None)
     if window is not None and k_len > window:
         raise NotImplementedError("sliding-window attention layers (Gemma3 local layers) are outside this path: the dense kernel "
                                   "attends globally (reference attention/attn.py:99-190 handles them with a hybrid cache)")
-    if query.is_cuda:
-        from . import ops
-        if dropout:
-            raise ops.KvzError("kvz_flash_fwd has no dropout (inference path)")
-        if not (query.dtype in (torch.float16, torch.bfloat16) and query.shape[0] == 1 and query.shape[-1] in (64, 128)
-                and key.shape[1] <= 64):
-            raise ops.KvzError(f"dense attention on the device needs fp16 / bf16, batch 1, head_dim 64 or 128 and <= 64 KV heads "
-                               f"(got {query.dtype}, batch {query.shape[0]}, head_dim {query.shape[-1]}, {key.shape[1]} KV heads): "
-                               "there is no generic fallback in the product path")
-        return ops.flash_fwd(query, key, value, causal=True, softmax_scale=scaling), None
-    mask, causal = None, False
-    if q_len == k_len:
-        causal = q_len > 1
-    elif q_len > 1:
-        from torch.nn.attention.bias import causal_lower_right
-        mask = causal_lower_right(q_len, k_len)
-    out = F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scaling,
-                                         enable_gqa=G > 1)
-    return out.transpose(1, 2), None
+    from . import ops
+    if not query.is_cuda:
+        raise ops.KvzError("dense attention runs on the library's HIP kernels only: the product path has no CPU implementation")
+    if dropout:
+        raise ops.KvzError("kvz_flash_fwd has no dropout (inference path)")
+    if not (query.dtype in (torch.float16, torch.bfloat16) and query.shape[0] == 1 and query.shape[-1] in (64, 128)
+            and key.shape[1] <= 64):
+        raise ops.KvzError(f"dense attention on the device needs fp16 / bf16, batch 1, head_dim 64 or 128 and <= 64 KV heads "
+                           f"(got {query.dtype}, batch {query.shape[0]}, head_dim {query.shape[-1]}, {key.shape[1]} KV heads): "
+                           "there is no generic fallback in the product path")
+    return ops.flash_fwd(query, key, value, causal=True, softmax_scale=scaling), None
 
 
 def register_attention_interface():

@@ -88,13 +88,15 @@ static void prof_collect() {
 
 // ---- tuning knobs --------------------------------------------------------------------------------------------------------
 namespace kvz {
-static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks"};
+static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd"};
 // attn_items: work items the key ranges of a decode call are cut into (128 / 192 / 256 / 384 measured in round 2,
 //   profiles/r2_attn_items.txt: 192 is best or within 1 % of the best on uniform, AdaKV-ragged and head-level caches);
 // flash_min_rows: query rows per head above which the multi-row kernels take over from the split-key decode kernel;
-// flash2_min_blocks: (head, 256-row tile) blocks from which the 32-row dense forward is used instead of the 16-row one.
-static const int g_tune_default[TUNE_COUNT] = {192, 64, 128};
-static int g_tune[TUNE_COUNT] = {192, 64, 128};
+// flash2_min_blocks: (head, 256-row tile) blocks from which the 32-row dense forward is used instead of the 16-row one;
+// flash2_xcd: 1 = XCD-aware block order of the 32-row dense forward (a head's row tiles on 8 / Hkv XCDs), 0 = head-major grid.
+// NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
+static const int g_tune_default[TUNE_COUNT] = {192, 64, 128, 1};
+static int g_tune[TUNE_COUNT] = {192, 64, 128, 1};
 int tunable(Tunable t) { return g_tune[t]; }
 }  // namespace kvz
 extern "C" int kvz_debug_set_tunable(const char* name, int value) {
@@ -102,7 +104,8 @@ extern "C" int kvz_debug_set_tunable(const char* name, int value) {
     for (int i = 0; i < kvz::TUNE_COUNT; ++i)
         if (strcmp(name, kvz::g_tune_name[i]) == 0) {
             const int prev = kvz::g_tune[i];
-            kvz::g_tune[i] = value > 0 ? value : kvz::g_tune_default[i];
+            // (value <= 0 restores the default; the on / off knob flash2_xcd takes 0 as "off" and negative values as "default")
+            kvz::g_tune[i] = (value > 0 || (i == kvz::TUNE_FLASH2_XCD && value == 0)) ? value : kvz::g_tune_default[i];
             return prev;
         }
     kvz::set_error("kvz_debug_set_tunable: unknown knob '%s'", name);
@@ -255,13 +258,44 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
 }
 
 
-// one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache on the caller's stream, then score
+// one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache, then score
 extern "C" int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, void* k_cache, void* v_cache,
                                           int64_t cache_head_stride, int fill, const void* k_state, const void* v_state,
                                           int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride,
                                           int64_t vs_row_stride, int t, const void* q, int64_t q_head_stride, int sink, int start,
                                           int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out,
-                                          int64_t log_head_stride, void* ws, size_t ws_bytes) {
+                                          int64_t log_head_stride, void* ws, size_t ws_bytes, int append_in_kernel) {
+    if (append_in_kernel && t == q_len && ks_row_stride == D) {
+        // the row-statistics pass stages the repeat chunk's K rows straight from k_state and its blocks write them, and the V
+        // rows, into the caches after their last tile: no append launch, nothing on the caller's stream but the "inputs ready"
+        // event.  Whoever reads rows fill .. fill + t of the caches afterwards must be ordered behind this slot (kvz_async_wait).
+        kvz::AsyncCtx* c = kvz::async_get(handle);
+        KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_update_score_async_log: bad handle %d", handle);
+        KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_update_score_async_log: bad slot %d", slot);
+        KVZ_REQUIRE(k_cache && v_cache && k_state && v_state && fill >= 0 && (int64_t)(fill + t) * D <= cache_head_stride, KVZ_EINVAL,
+                    "kvz_update_score_async_log: bad append (rows %d..%d of a head of %lld elements)", fill, fill + t, (long long)cache_head_stride);
+        if (side != caller) {
+            if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
+                hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess ||
+                // (the previous call of the slot read - and wrote - the same cache rows; normally it ran on this very side stream)
+                (c->pending[slot] && hipStreamWaitEvent((hipStream_t)side, c->done[slot], 0) != hipSuccess)) {
+                kvz::set_error("kvz_update_score_async_log: could not order the side stream");
+                return KVZ_ELAUNCH;
+            }
+        }
+        const int rc = kvz::score_chunk_log_append(q, q_head_stride, k_cache, v_cache, cache_head_stride, fill + t, k_state, ks_head_stride,
+                                                   v_state, vs_head_stride, vs_row_stride, sink, start, end, q_len, Hkv, G, D, dtype,
+                                                   log_out, log_head_stride, ws, ws_bytes, (hipStream_t)side);
+        if (rc != KVZ_OK) return rc;
+        if (side != caller) {
+            if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {
+                kvz::set_error("kvz_update_score_async_log: hipEventRecord failed");
+                return KVZ_ELAUNCH;
+            }
+            c->pending[slot] = 1;
+        }
+        return KVZ_OK;
+    }
     // the previous scoring call of this slot read the rows that the append overwrites
     int rc = kvz_async_wait(handle, slot, caller);
     if (rc != KVZ_OK) return rc;

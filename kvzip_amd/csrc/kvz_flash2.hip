@@ -51,6 +51,7 @@ struct Flash2Args {
     int Hkv, G, q_len, causal;
     float scale;
     int n_rt;                         // row tiles per head
+    int xcd_mode, xcd_par;            // block -> (head, row tile) mapping, see the kernel
     // scoring window (f2: the row statistics of KVScore._get_score come out of the forward's own QK^T tiles): keys [0, win_sink) ++
     // [win_start, win_end) ++ the last q_len keys of the segment; win_stats [Hkv, win_stats_stride] float2 (m_r, l'_r), row index
     // g*q_len + i (the layout the column-maximum pass reads)
@@ -61,7 +62,7 @@ struct Flash2Args {
 };
 
 template <typename T, bool WIN, bool FAST>
-__global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a) {
+__global__ __launch_bounds__(F2_THREADS, 1) void flash2_fwd_kernel(Flash2Args a) {
     typedef typename Mfma32<T>::v8 v8;
     constexpr int D = 128, ROW_BYTES = D * 2, KK = D / 16, DB = D / 32;
     constexpr int TILE_BYTES = F2_KT * ROW_BYTES;                 // 16 KiB (K or V)
@@ -71,8 +72,29 @@ __global__ __launch_bounds__(F2_THREADS, 2) void flash2_fwd_kernel(Flash2Args a)
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
 
-    const int h = blockIdx.y;
-    const int rt = a.n_rt - 1 - (int)blockIdx.x;  // heaviest row tiles (longest causal prefixes) first
+    // ---- block -> (head, row tile), XCD-aware (round 4).  Workgroup b runs on XCD b % 8 and every XCD has its own 4-MiB L2: with
+    // the row tiles of a head spread over all eight XCDs (the plain 2-D grid of round 3) every XCD pulled every head's K and V
+    // through the fabric - 2.46 GB of fabric reads for 0.30 GB of inputs at the scoring forward's shape
+    // (profiles/r3_pmc_traffic.json).  Now a head's row tiles run on 8 / Hkv XCDs (Hkv <= 8) or an XCD owns Hkv / 8 whole heads;
+    // inside a head's XCD group the row tiles are dealt round-robin, so the causal prefixes stay balanced over the XCDs, and
+    // in dispatch order the heaviest row tiles (longest causal prefixes) still come first.
+    int h, xt;
+    {
+        const int b = (int)blockIdx.x, c = b & 7, sl = b >> 3;
+        if (a.xcd_mode == 1) {        // xcd_par = XCDs per head
+            h = c / a.xcd_par;
+            xt = sl * a.xcd_par + (c - h * a.xcd_par);
+        } else if (a.xcd_mode == 2) { // xcd_par = heads per XCD
+            const int hs = sl / a.n_rt;
+            h = c * a.xcd_par + hs;
+            xt = sl - hs * a.n_rt;
+        } else {                      // head-major (what the 2-D grid did)
+            h = b / a.n_rt;
+            xt = b - h * a.n_rt;
+        }
+        if (xt >= a.n_rt || h >= a.Hkv) return;  // (padding blocks of mode 1 when 8 / Hkv does not divide the row tiles)
+    }
+    const int rt = a.n_rt - 1 - xt;
     const int R = a.q_len * a.G;
     const int len = (a.n_meta ? a.m_len[h] : a.k_len[h]) + a.k_len_offset;
     const int64_t seg = a.n_meta ? a.m_start[h] : a.k_start[h];
@@ -381,7 +403,17 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
     a.win_stats = reinterpret_cast<float2*>(win_stats); a.win_stats_stride = win_stats_head_stride;
     a.win_c = sqrtf(128.f);
     a.win_rcp = win_stats ? score_exact_reciprocal(128, dtype) : 0.f;
-    const dim3 grid(a.n_rt, Hkv), block(F2_THREADS);
+    int n_blocks = a.n_rt * Hkv;
+    a.xcd_mode = 0; a.xcd_par = 1;
+    if (tunable(TUNE_FLASH2_XCD) != 0) {
+        if (Hkv <= 8 && 8 % Hkv == 0) {
+            a.xcd_mode = 1; a.xcd_par = 8 / Hkv;
+            n_blocks = 8 * ((a.n_rt + a.xcd_par - 1) / a.xcd_par);
+        } else if (Hkv % 8 == 0) {
+            a.xcd_mode = 2; a.xcd_par = Hkv / 8;
+        }
+    }
+    const dim3 grid(n_blocks), block(F2_THREADS);
     ProfScope ps("flash_fwd", stream);
 #define KVZ_F2_LAUNCH(T, WIN, FAST) hipLaunchKernelGGL((flash2_fwd_kernel<T, WIN, FAST>), grid, block, 0, stream, a)
     if (!win_stats) {

@@ -36,14 +36,8 @@
 namespace kvz {
 
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
-#ifndef KVZ_PB_WAVES
-#define KVZ_PB_WAVES 8   // round 2: one 8-wave block per CU (three 32-KiB row-tile buffers; 4 LDS-DMA pieces per wave and tile)
-#endif
-#ifndef KVZ_PB_OCC
-#define KVZ_PB_OCC (KVZ_PB_WAVES / 4)
-#endif
-constexpr int PB_WAVES = KVZ_PB_WAVES;   // waves per block of pass B
-constexpr int PB_OCC = KVZ_PB_OCC;       // waves per SIMD the register budget is sized for
+constexpr int PB_WAVES = 8;              // waves per block of pass B: one 8-wave block per CU (three 32-KiB row-tile buffers; 4 LDS-DMA pieces per wave and tile)
+constexpr int PB_OCC = PB_WAVES / 4;     // waves per SIMD the register budget is sized for
 // division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
 // l = ceil(log2 d) (Granlund-Montgomery round-up method, exact for 31-bit numerators).  A 32-bit division costs ~20 instructions;
 // the item switch of pass A had nine of them, executed by all eight waves.
@@ -84,6 +78,15 @@ struct ScoreArgs {
     FastDiv dq, dh;      // q_len, Hkv
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
+    // in-kernel append (round 4; reference EvictCache.update, attention/kvcache.py:41-80, in front of _get_score): the repeat
+    // chunk's K rows are NOT in the cache yet - pass A stages them from `krep` ([Hkv, q_len, D], rows contiguous) and the blocks of
+    // pass B copy them, and the chunk's V rows, into rows klen - q_len .. klen - 1 of the K / V caches after their tile loop.
+    // NULL: the rows are in the cache already (a separate append launch, or a plain scoring call).
+    const void* krep;
+    int64_t krep_head_stride;      // elements
+    void* app_v;                   // V cache [Hkv, cache head stride = k_head_stride, D]
+    const void* vrep;              // [Hkv, q_len, D] with element strides (head, row)
+    int64_t vrep_head_stride, vrep_row_stride;
 };
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
@@ -191,9 +194,9 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 //
 // Execution shape (from in-kernel s_memtime traces, per-block Gantt charts and ablations: DESIGN.md 3.1, profiles/r*_timeline.txt):
 //  * one 8-wave block per CU (two waves per SIMD), 32 query rows per wave, 256 rows per key tile: half the L2->LDS
-//    traffic per logit of a 128-row block.  (KVZ_PA_WAVES=4 / KVZ_PA_RG=2 builds the one-wave-per-SIMD variant with 64 rows per
-//    wave: measured 27 % slower in round 3 even with the query rows in the accumulator file - a lone wave cannot fill its own
-//    dependency stalls, profiles/r3_ab_one_wave_per_simd.txt.)
+//    traffic per logit of a 128-row block.  (The one-wave-per-SIMD variant with 64 rows per wave measured 27 % slower in round 3
+//    even with the query rows in the accumulator file - a lone wave cannot fill its own dependency stalls,
+//    profiles/r3_ab_one_wave_per_simd.txt.)
 //  * No global load with a register destination inside the kernel: key tiles AND the query rows of the next item come
 //    in by LDS-DMA issued from assembly.  A load the compiler knows about makes it place s_waitcnt vmcnt(n) wherever
 //    one of the affected registers is touched, and because the hardware counter also holds the DMA, every such wait
@@ -204,14 +207,8 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 //    one 32-key block ahead into a second register set (a prefetch into the registers the chain in flight still
 //    reads stalls the in-order issue), and the hand-over barrier sits right after the LAST matrix chain of a tile
 //    has been issued, not after its epilogue.  The tile stream runs across item boundaries.
-#ifndef KVZ_PA_WAVES
-#define KVZ_PA_WAVES 8
-#endif
-#ifndef KVZ_PA_RG
-#define KVZ_PA_RG 1
-#endif
-constexpr int PA_WAVES = KVZ_PA_WAVES;
-constexpr int PA_RG = KVZ_PA_RG;                // 32-row groups per wave
+constexpr int PA_WAVES = 8;
+constexpr int PA_RG = 1;                        // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
 
 // ---- the instruction stream of a wave (round 2: software pipeline inside the wave) --------------------------------------
@@ -227,33 +224,17 @@ constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
 //   * fp16: rounding chain and exponent argument of FOUR logits are one assembly block of 8 instructions ordered so that
 //     every consumer of a 16-bit (dst_sel) write is at least one instruction behind it (no s_nop).
 // Placement of the KK MFMAs of a chain over the 8 half-groups of a pipeline step (half-group = 2 x quad index + half).
-// KVZ_SCHED 1 (default): the chain ends one half-group early - the next step starts by reading this accumulator, and a chain
-// that ends with the step makes it wait for the last MFMA (the compiler pads 12 wait states) - by issuing the first two
-// MFMAs back to back (dependent MFMAs issued back to back take the accumulator forwarding path).
-// KVZ_SCHED 0: one MFMA per half-group.
-#ifndef KVZ_SCHED
-#define KVZ_SCHED 1
-#endif
-#ifndef KVZ_PRIO          // 1: the second-dispatched half of a block gets priority in every other step (it loses VALU arbitration by age)
-#define KVZ_PRIO 1
-#endif
-#ifndef KVZ_BF16_PACKED   // 1: bf16 rounding chain on pairs (packed conversions and packed fp32 multiplies)
-#define KVZ_BF16_PACKED 1
-#endif
-#ifndef KVZ_CVT_IN_ASM    // 1: the first conversion of the chain inside the assembly block too
-#define KVZ_CVT_IN_ASM 1
-#endif
-#ifndef KVZ_CHAIN_MIX16   // 1: second rounding of the chain by v_fma_mixlo/hi_f16 (round 1); 0: fp32 product + v_cvt_pk_f16_f32
-#define KVZ_CHAIN_MIX16 0
-#endif
+// The chain ends one half-group early - the next step starts by reading this accumulator, and a chain that ends with the step
+// makes it wait for the last MFMA (the compiler pads 12 wait states) - by issuing the first two MFMAs back to back (dependent
+// MFMAs issued back to back take the accumulator forwarding path).
 template <int KK> struct MfmaSched {
     // first k-step and number of k-steps issued in half-group hg
     __device__ static constexpr int first(int hg) {
-        if (KK == 8) return KVZ_SCHED ? (hg == 0 ? 0 : hg + 1) : hg;
+        if (KK == 8) return hg == 0 ? 0 : hg + 1;
         return hg / 2;  // KK == 4: even half-groups only
     }
     __device__ static constexpr int count(int hg) {
-        if (KK == 8) return KVZ_SCHED ? (hg == 0 ? 2 : (hg == 7 ? 0 : 1)) : 1;
+        if (KK == 8) return hg == 0 ? 2 : (hg == 7 ? 0 : 1);
         return (hg & 1) ? 0 : 1;
     }
 };
@@ -261,7 +242,6 @@ template <typename T, bool FAST>
 __device__ static inline void quad_args(float a0, float a1, float a2, float a3, uint32_t& xa, uint32_t& xb, float (&arg)[4],
                                         float c, float rcp, float L2E /* multiplier of x */, float neg_ml2 /* addend */) {
     if constexpr (std::is_same<T, _Float16>::value && FAST) {
-#if !KVZ_CHAIN_MIX16 && KVZ_CVT_IN_ASM
         // the first rounding inside the block as well: left outside, the compiler converts all 16 accumulators at the top of the
         // step and keeps the 8 packed results (and a copy per quad) alive - registers the 64-row kernel does not have
         asm("v_cvt_pk_f16_f32 %[xa], %[a0], %[a1]\n\t"
@@ -279,22 +259,8 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
             : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
         return;
-#endif
         xa = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a0, a1}, h2v));
         xb = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a2, a3}, h2v));
-#if KVZ_CHAIN_MIX16
-        // second rounding by v_fma_mixlo/hi_f16 (quarter rate: 8 cycles each)
-        asm("v_fma_mixlo_f16 %[xa], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mixlo_f16 %[xb], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mixhi_f16 %[xa], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mixhi_f16 %[xb], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g0], %[xa], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-            : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
-            : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
-#else
         // second rounding as fp32 product (v_fma_mix_f32 reads the half, half rate) + v_cvt_pk_f16_f32 (two per instruction):
         // 6.6 instead of 8.1 cycles per logit.  The four products land in the argument registers, which the last four
         // instructions then overwrite with the exponent arguments (every consumer is >= 2 instructions behind its producer).
@@ -310,8 +276,7 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
             "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
             : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
             : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
-#endif
-    } else if constexpr (std::is_same<T, __bf16>::value && FAST && KVZ_BF16_PACKED) {
+    } else if constexpr (std::is_same<T, __bf16>::value && FAST) {
         // bf16: there is no mixed-precision fma that reads a bf16 half, so every value goes f32 -> bf16 -> f32 twice.  Written on
         // pairs: v_cvt_pk_bf16_f32 rounds two values per instruction, the way back is a shift / a mask, and the two fp32
         // multiplications (by rcp, then by log2e with the addend) are packed v_pk_mul_f32 / v_pk_fma_f32: 16 instead of the 24
@@ -394,12 +359,10 @@ __host__ __device__ static inline int plan_ntiles(int rt, int rows, int R, int q
     const int qmax = (r0 / q_len == r1 / q_len) ? (r1 % q_len) : (q_len - 1);
     return (sink + m + qmax + 1 + SC_TILE - 1) / SC_TILE;
 }
-#ifndef KVZ_PLAN_SWITCH_Q   // cost model of the partition, in quarter key tiles: entering a unit (query rows, first chain,
-#define KVZ_PLAN_SWITCH_Q 0  // bookkeeping) and a key tile that reaches into the causal zone of the unit's rows (the block waits for
-#endif                       // the waves that run the masked epilogue: 1.45 x); a plain tile costs 4
-#ifndef KVZ_PLAN_MASKED_Q
-#define KVZ_PLAN_MASKED_Q 6  // (4 / 6 / 8 and a switch cost of 0 / 4 / 6 / 12 measured: within 1 % of each other, 6 / 0 best)
-#endif
+// cost model of the partition, in quarter key tiles: entering a unit (query rows, first chain, bookkeeping) and a key tile that
+// reaches into the causal zone of the unit's rows (the block waits for the waves that run the masked epilogue: 1.45 x); a plain
+// tile costs 4  (4 / 6 / 8 and a switch cost of 0 / 4 / 6 / 12 measured: within 1 % of each other, 6 / 0 best)
+constexpr int PLAN_SWITCH_Q = 0, PLAN_MASKED_Q = 6;
 // does key tile t hold the causal limit of some row of row tile rt?  (those rows' wave runs the masked epilogue there and the
 // other waves of the block wait for it at the hand-over)  The rows of a row tile are one or two runs of consecutive positions.
 static inline bool plan_tile_masked(int rt, int t, int rows, int R, int q_len, int sink, int m) {
@@ -413,7 +376,7 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
     const int R = G * q_len, RT = (R + rows - 1) / rows;
     const int64_t U = (int64_t)RT * Hkv;
     if (U > 65535 || (sink + m + q_len) / SC_TILE + 1 > 65535) return false;
-    constexpr int SW = KVZ_PLAN_SWITCH_Q, MQ = KVZ_PLAN_MASKED_Q;
+    constexpr int SW = PLAN_SWITCH_Q, MQ = PLAN_MASKED_Q;
     // cost of the first t tiles of row tile rt (entering included)
     auto cost = [&](int rt, int t) -> int64_t {
         int64_t c = SW;
@@ -476,23 +439,6 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
     return true;
 }
 
-// optional in-kernel timeline (-DKVZ_TRACE=1, tools/trace2.py): s_memtime stamps of ONE block per 32, all 8 waves, 8 stamps per
-// tile = start of the four steps, arrival at / release from the hand-over barrier, end of the hand-over, end of the tile
-#ifndef KVZ_TRACE
-#define KVZ_TRACE 0
-#endif
-#ifndef KVZ_ABL   // time-attribution builds of the row-statistics kernel (tools/abl_time.py; their results are garbage): bit 0 no
-#define KVZ_ABL 0  // fragment reads, 1 no exponentials, 2 no MFMA, 3 no staging, 4 no barrier, 5 no rounding chain
-#endif
-
-#if KVZ_TRACE
-__device__ unsigned long long g_trace_b[8 * 8 * 20 * 8];   // pass B: 8 blocks x 8 waves x 20 tiles x 8 stamps (+ slot 19: prologue / epilogue)
-__device__ unsigned long long g_trace2[8 * 8 * 40 * 16];
-#define KVZ_STAMP(i) do { ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define KVZ_STAMP(i) do { } while (0)
-#endif  // a block whose exponentials (vs the reference) sum to more moves the reference
-
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a, PaPlan plan) {
     constexpr int NWAVES = PA_WAVES;
@@ -551,6 +497,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     const uint32_t lds0 = lds_addr(lds);
     const char* const kbase = reinterpret_cast<const char*>(a.k);
     const int64_t khs = a.k_head_stride * 2;
+    const char* const krep0 = reinterpret_cast<const char*>(a.krep);  // null: the repeat chunk's rows are in the cache
+    const int64_t kreps = a.krep_head_stride * 2;
     auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
         const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
         const char* kh = kbase + (int64_t)h * khs;
@@ -561,9 +509,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         else if (t >= tr_lo && t < tr_hi) off = off_rep;
         else if (t >= ts_hi) linear = false;
         if (linear) {
-            stage_tile_linear_a<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
+            const bool rep_tile = krep0 != nullptr && t >= tr_lo && t < tr_hi;  // (wave-uniform)
+            const char* base = rep_tile ? krep0 + (int64_t)h * kreps + (int64_t)(kv0 - diag0) * C::ROW_BYTES
+                                        : kh + (int64_t)(kv0 + off) * C::ROW_BYTES;
+            stage_tile_linear_a<D, NWAVES>(dst, base, lane_off, wave);
         } else {  // (inlined: a call would open with s_waitcnt vmcnt(0) and drain the tiles in flight)
             constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+            const char* const krh = krep0 ? krep0 + (int64_t)h * kreps : nullptr;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int ci = i * NWAVES + wave;  // wave-uniform 1-KiB piece of the tile
@@ -571,8 +523,16 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                 const int pch = lane % C::CPR;
                 const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
                 const int kv = min(kv0 + row, KT - 1);
-                const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
-                lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
+                if (krh) {
+                    // the repeat chunk's rows come from another allocation: a 64-bit address per lane (tiles that straddle a
+                    // segment boundary or the end only - at most three per item)
+                    const int crow = kv + (kv < a.sink ? 0 : off_ctx);
+                    const char* src = (kv < diag0 ? kh + (int64_t)crow * C::ROW_BYTES : krh + (int64_t)(kv - diag0) * C::ROW_BYTES) + chunk * 16;
+                    lds_dma16v(src, dst + (uint32_t)(ci * 1024));
+                } else {
+                    const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
+                    lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
+                }
             }
         }
     };
@@ -647,9 +607,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     };
     // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates
     auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
-#if KVZ_ABL & 1   // (time attribution only: the fragments are read once per item)
-        if (!abl_first) return;
-#endif
         frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
     };
     typedef std::integral_constant<int, 0> I0;
@@ -725,12 +682,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     };
     start_item();
 
-#if KVZ_TRACE
-    unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 8..15: the item switch BEFORE this tile
-    const bool tracing = (blockIdx.x % 32 == 5) && lane == 0;
-    unsigned long long* tr = g_trace2 + (((blockIdx.x / 32) % 8) * 8 + wave) * (40 * 16);
-    int tp = 0;
-#endif
     f16v acc[2][PA_RG];  // accumulators of block kb (index kb & 1)
     const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -761,11 +712,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
                     for (int g = 0; g < PA_RG; ++g) {
                         const int kk = MfmaSched<C::KK>::first(2 * qd) + c;
-#if KVZ_ABL & 4
-                        accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
-#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], kk == 0 ? zero16 : accn[g]);
-#endif
                     }
             }
 #pragma unroll
@@ -776,12 +723,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                     const int i = qd * 4 + j;
                     v[j] = (!MASK || (i & 3) + 8 * (i >> 2) <= rel[g]) ? accc[g][i] : -INFINITY;  // -inf survives the chain
                 }
-#if KVZ_ABL & 32
-                arg[g][0] = v[0]; arg[g][1] = v[1]; arg[g][2] = v[2]; arg[g][3] = v[3];
-                xp[g][2 * qd] = xp[g][2 * qd + 1] = 0;
-#else
                 quad_args<T, FAST>(v[0], v[1], v[2], v[3], xp[g][2 * qd], xp[g][2 * qd + 1], arg[g], a.c, a.rcp, L2E, nml2_ref[g]);
-#endif
             }
             // -- second half: (second MFMA,) the four exponentials and their sums
             __builtin_amdgcn_sched_barrier(0);
@@ -791,20 +733,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
                     for (int g = 0; g < PA_RG; ++g) {
                         const int kk = MfmaSched<C::KK>::first(2 * qd + 1) + c;
-#if KVZ_ABL & 4
-                        accn[g][kk] += __builtin_bit_cast(float, frn[kk][0]);
-#else
                         accn[g] = Mfma32<T>::mfma(__builtin_bit_cast(v8, frn[kk]), bq[g][kk], accn[g]);
-#endif
                     }
             }
-#if KVZ_ABL & 2
-#pragma unroll
-            for (int g = 0; g < PA_RG; ++g) { ps0[g] += arg[g][0] + arg[g][2]; ps1[g] += arg[g][1] + arg[g][3]; }
-#else
 #pragma unroll
             for (int g = 0; g < PA_RG; ++g) quad_sum(arg[g], ps0[g], ps1[g]);
-#endif
             if (qd == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 hook();
@@ -814,11 +747,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g) {
             float ps = ps0[g] + ps1[g];
-#if KVZ_ABL
-            if (false) {
-#else
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0, 0)) {  // wave-uniform and rare: move the reference, redo
-#endif
                 asm volatile("" ::: "memory");                                                 // (keeps it a branch)
                 const float tmax = max_packed16<T>(xp[g]);
                 // up: a logit far above the reference; down (first block of an item only, nothing summed yet): all logits far below
@@ -863,72 +792,35 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             ++staged;
         }
         if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
-#if KVZ_ABL & 8
-            if (sp < 1)
-#endif
             sq_stage(B2);
             ++staged;
             newer = 1;
         }
-        KVZ_STAMP(4);
-#if !(KVZ_ABL & 16)
         if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // the next tile (and older pieces) landed
         else stage_wait();
         block_barrier();  // ... everybody's part has, and nobody reads tile B any more
-#endif
-        KVZ_STAMP(5);
         next_ready = staged >= sp + 2;
         if (next_ready) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
-        KVZ_STAMP(6);
     };
     auto tile_steps = [&](auto b_tag, auto mask_tag) __attribute__((always_inline)) {
         constexpr int B = decltype(b_tag)::value;
         constexpr int B1 = (B + 1) % RING;
         const int k0 = t * SC_TILE;
-        KVZ_STAMP(0);
-        // the second-dispatched half of the block loses VALU arbitration by age: KVZ_PRIO 1 gives it priority in steps 0 and 2,
-        // 2 in steps 0-2, 3 always (set once before the loop), 4 in steps 1 and 3
+        // the second-dispatched half of the block loses VALU arbitration by age: it gets priority in steps 0 and 2 (the other
+        // patterns - steps 0-2, always, steps 1 and 3 - measured within +-1 %, profiles/r3_passA_timeline.txt)
         const bool young = wave >= NWAVES / 2;
-#if KVZ_PRIO == 1 || KVZ_PRIO == 2
         if (young) __builtin_amdgcn_s_setprio(1);
-#endif
         step(acc[1], acc[0], fr[1], k0, (t == cur.t_lo) ? PA2_SUM_LOW : 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
-#if KVZ_PRIO == 1
         if (young) __builtin_amdgcn_s_setprio(0);
-#elif KVZ_PRIO == 4
-        if (young) __builtin_amdgcn_s_setprio(1);
-#endif
-        KVZ_STAMP(1);
         step(acc[0], acc[1], fr[0], k0 + 32, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
-        KVZ_STAMP(2);
-#if KVZ_PRIO == 1
         if (young) __builtin_amdgcn_s_setprio(1);
-#elif KVZ_PRIO == 4
-        if (young) __builtin_amdgcn_s_setprio(0);
-#endif
         step(acc[1], acc[0], fr[1], k0 + 64, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
-#if KVZ_PRIO == 1 || KVZ_PRIO == 2
         if (young) __builtin_amdgcn_s_setprio(0);
-#elif KVZ_PRIO == 4
-        if (young) __builtin_amdgcn_s_setprio(1);
-#endif
-        KVZ_STAMP(3);
         // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
         // (one variant less of every tile body; the matrix pipe has the slack)
         step(acc[0], acc[1], fr[0], k0 + 96, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) {
             if (next_ready) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
         });
-#if KVZ_PRIO == 4
-        if (young) __builtin_amdgcn_s_setprio(0);
-#endif
-        KVZ_STAMP(7);
-#if KVZ_TRACE
-        if (tracing && tp < 40) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tr[tp * 16 + i] = ts[i];
-            ++tp;
-        }
-#endif
     };
     auto tile_dispatch = [&](auto b_tag) __attribute__((always_inline)) {
         int wm = wmin[0];
@@ -964,15 +856,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             frag_load<D>(fr[1], fa0, b1 * C::TILE_BYTES + 32 * C::ROW_BYTES);
         }
     };
-    (void)diag0;
 
-#if KVZ_PRIO == 3
-    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     chain0(acc[0], fr[0]);
-#if KVZ_ABL & 1
-    abl_first = false;
-#endif
     while (true) {
         if (t >= t_hidden) tile_skip();
         else if (pbuf == 0) tile_dispatch(I0{});
@@ -982,7 +867,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         ++sp;
         ++t;
         if (t < cur.t_hi) continue;  // (acc[0] already holds block 0 of the next tile)
-        KVZ_STAMP(8);
 
         // ---- item finished: partial statistics of this key slice (reference m_ref, sum relative to fl(m_ref*log2e)) ----
 #pragma unroll
@@ -1007,7 +891,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             const int val = cur.z + 1;
             asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(val) : "memory");
         }
-        KVZ_STAMP(9);
         if (!valid(nxt)) break;
         // ---- switch to the next item: fragments of its first two blocks are in registers, its query rows landed before the
         // last hand-over ----
@@ -1017,16 +900,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         for (int g = 0; g < PA_RG; ++g)
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[g][kk]));
-        KVZ_STAMP(10);
         chain0(acc[0], fr[0]);  // (the eight dependent MFMAs run under the index arithmetic below)
-        KVZ_STAMP(11);
         nxt = item_from(cur.k + 1);
         t = cur.t_lo;
-        KVZ_STAMP(12);
         rows = rows_of(cur);
-        KVZ_STAMP(13);
         if (valid(nxt)) stage_q(nxt);
-        KVZ_STAMP(14);
         if (sq_in_next) {  // the cursor was already inside the item that is now current
             sq_in_next = false;
             if (sq_done && valid(nxt)) {
@@ -1036,7 +914,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             }
         }
         start_item();
-        KVZ_STAMP(15);
     }
 }
 
@@ -1047,10 +924,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 // quad_args); blocks alternate between "hold" and "v_max3(best, hold, t)" so that two blocks share one maximum per key.
 // Round 3: the partial statistics of pass A are merged in the PROLOGUE of this kernel (each block merges the segments of its own
 // row slice into LDS: bit-identical to the former merge launch, which is gone together with the per-tile statistics DMA).
-#ifndef KVZ_PB_RG
-#define KVZ_PB_RG 1
-#endif
-constexpr int PB_RG = KVZ_PB_RG;                 // groups of 32 stationary keys per wave
+constexpr int PB_RG = 1;                         // groups of 32 stationary keys per wave
 constexpr int PB_COLS = PB_WAVES * PB_RG * 32;   // stationary ctx keys per block
 constexpr int PB_STAT_TILES = 56;                // row tiles per block whose merged statistics fit beside the ring (56 KiB)
 
@@ -1068,6 +942,33 @@ __device__ static inline float2 merge_row_stats(const float2* __restrict__ stats
     const float delta = __builtin_fmaf(M, L2E, -ML2);
     return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
+// ---- in-kernel append (round 4): this block's share of the repeat chunk's K and V rows -> rows klen - q_len .. of the caches.
+// Called by every block of pass B after its tile loop (no LDS-DMA in flight any more, the kernel has register room, and pass A -
+// which read the K rows from `krep` - is over): 2 * Hkv * q_len rows over ~256 blocks = 16 KiB per block.
+template <int D>
+__device__ static inline void score_append_rows(const ScoreArgs& a, int nthreads) {
+    if (!a.krep) return;
+    constexpr int ROW_BYTES = D * 2, CPR = ROW_BYTES / 16;
+    const int64_t per_head = (int64_t)a.q_len * CPR;          // 16-byte chunks per head
+    const int64_t half_total = per_head * a.n_kv_heads;       // K, then as many for V
+    const int64_t total = 2 * half_total;
+    const int64_t share = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t c_end = min(total, (int64_t)(blockIdx.x + 1) * share);
+    const int fill = a.klen - a.q_len;
+    const int64_t khs = a.k_head_stride * 2, kreps = a.krep_head_stride * 2, vhs = a.vrep_head_stride * 2, vrs = a.vrep_row_stride * 2;
+    for (int64_t c = (int64_t)blockIdx.x * share + threadIdx.x; c < c_end; c += nthreads) {
+        const bool is_v = c >= half_total;
+        const int64_t cc = is_v ? c - half_total : c;
+        const int hh = (int)(cc / per_head);
+        const int rr = (int)((cc - hh * per_head) / CPR), ch = (int)(cc % CPR);
+        const char* src = is_v ? reinterpret_cast<const char*>(a.vrep) + hh * vhs + rr * vrs + ch * 16
+                               : reinterpret_cast<const char*>(a.krep) + hh * kreps + (int64_t)rr * ROW_BYTES + ch * 16;
+        char* dst = (is_v ? reinterpret_cast<char*>(a.app_v) : reinterpret_cast<char*>(const_cast<void*>(a.k))) + hh * khs +
+                    (int64_t)(fill + rr) * ROW_BYTES + ch * 16;
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    }
+}
+
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
@@ -1147,13 +1048,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
 #pragma unroll
         for (int i = 0; i < 16; ++i) best[g][i] = hold[g][i] = -INFINITY;
 
-#if KVZ_TRACE
-    unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool tracing = (blockIdx.x % 32 == 5) && lane == 0;
-    unsigned long long* tr = g_trace_b + (((blockIdx.x / 32) % 8) * 8 + wave) * (20 * 8);
-    int tp = 0;
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-#endif
     if (t_begin < t_end) {
         stage(0);
         // ---- merged statistics of the block's row slice -> LDS (the first tile is in flight meanwhile; the second one is issued
@@ -1277,43 +1171,25 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             const float2* const ls = lstat + (t - t_begin) * SC_TILE + l31;
 #pragma unroll
             for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = ls[kb * 32];
-            KVZ_STAMP(0);
             step(acc[1], acc[0], fr[1], st[0], std::false_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
-            KVZ_STAMP(1);
             step(acc[0], acc[1], fr[0], st[1], std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
-            KVZ_STAMP(2);
             step(acc[1], acc[0], fr[1], st[2], std::false_type{}, [&]() __attribute__((always_inline)) {
                 // hand-over: the tile two positions ahead goes into the buffer the previous hand-over freed, its DMA is issued
                 // BEFORE the barrier; the counted wait leaves exactly those pieces in flight
-                KVZ_STAMP(4);
                 if (t + 2 < t_end) {
                     stage(B2);
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
                 } else {
                     stage_wait();
                 }
-                KVZ_STAMP(5);
                 block_barrier();  // the next tile has landed for everybody, every fragment of this tile has been read
-                KVZ_STAMP(6);
                 if (t + 1 < t_end) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
             });
-            KVZ_STAMP(3);
             // (after the last tile the chain issued here is not used)
             step(acc[0], acc[1], fr[0], st[3], std::true_type{}, [&]() __attribute__((always_inline)) {
                 if (t + 1 < t_end) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
             });
-            KVZ_STAMP(7);
-#if KVZ_TRACE
-            if (tracing && tp < 19) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) tr[tp * 8 + i] = ts[i];
-                ++tp;
-            }
-#endif
         };
-#if KVZ_TRACE
-        if (tracing) { tr[19 * 8 + 0] = t_entry; tr[19 * 8 + 1] = __builtin_amdgcn_s_memtime(); }   // entry, start of the tile loop
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) mfma_step(acc[0], fr[0], kk);
@@ -1375,9 +1251,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             }
         }
     }
-#if KVZ_TRACE
-    if (tracing) { tr[19 * 8 + 2] = ts[7]; tr[19 * 8 + 3] = __builtin_amdgcn_s_memtime(); }   // end of the last tile, end of the kernel
-#endif
+    score_append_rows<D>(a, NWAVES * 64);
 }
 
 template <typename T>
@@ -1412,10 +1286,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int score_row_splits(int Hkv, int G, int q_len, int m) {
     const int ctiles = (m + PB_COLS - 1) / PB_COLS;
     const int rtiles = (G * q_len + SC_TILE - 1) / SC_TILE;
-#ifndef KVZ_PB_BLOCKS
-#define KVZ_PB_BLOCKS 256
-#endif
-    int splits = KVZ_PB_BLOCKS / (ctiles * Hkv);  // one round of resident blocks when the shape allows
+    int splits = 256 / (ctiles * Hkv);  // one round of resident blocks (256 CUs) when the shape allows
     const int need = (rtiles + PB_STAT_TILES - 1) / PB_STAT_TILES;
     if (splits < need) splits = need;
     if (splits > rtiles) splits = rtiles;
@@ -1589,10 +1460,18 @@ extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, in
     return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len);
 }
 
+// the repeat chunk's K,V that pass A appends to the caches itself (kvz_update_score_async_log with append_in_kernel)
+struct ScoreAppend {
+    const void* k_state;
+    const void* v_state;
+    void* v_cache;
+    int64_t ks_head_stride, vs_head_stride, vs_row_stride;  // elements
+};
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0);
+                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0,
+                            const ScoreAppend* app = nullptr);
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                                int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
@@ -1608,6 +1487,17 @@ extern "C" int kvz_score_chunk_log(const void* q, int64_t q_head_stride, const v
     KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_chunk_log: bad log buffer");
     return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
                             log_head_stride, ws, ws_bytes, stream_);
+}
+
+// scoring call whose pass A also appends the repeat chunk's K,V (k_state rows contiguous) to rows klen - q_len .. of the caches
+int kvz::score_chunk_log_append(const void* q, int64_t q_head_stride, void* k_cache, void* v_cache, int64_t cache_head_stride, int klen,
+                                const void* k_state, int64_t ks_head_stride, const void* v_state, int64_t vs_head_stride,
+                                int64_t vs_row_stride, int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
+                                uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, hipStream_t stream) {
+    KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_update_score_async_log: bad log buffer");
+    const ScoreAppend app{k_state, v_state, v_cache, ks_head_stride, vs_head_stride, vs_row_stride};
+    return score_chunk_impl(q, q_head_stride, k_cache, cache_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0,
+                            log_out, log_head_stride, ws, ws_bytes, (kvz_stream_t)stream, nullptr, 0, &app);
 }
 
 extern "C" int kvz_score_from_stats_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -1643,7 +1533,7 @@ extern "C" int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out,
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride) {
+                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride, const ScoreAppend* app) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && (out || log_out) && (ws || merged_stats), KVZ_EINVAL, "kvz_score_chunk: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
@@ -1677,6 +1567,15 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     }
     a.out = out; a.out_head_stride = out_head_stride;
     a.log_out = log_out; a.log_head_stride = log_head_stride;
+    if (app) {
+        KVZ_REQUIRE(!merged_stats && app->k_state && app->v_state && app->v_cache, KVZ_EINVAL, "kvz_score_chunk: bad in-kernel append");
+        KVZ_REQUIRE(aligned16(app->k_state) && aligned16(app->v_state) && aligned16(app->v_cache) &&
+                        (app->ks_head_stride * 2) % 16 == 0 && (app->vs_head_stride * 2) % 16 == 0 && (app->vs_row_stride * 2) % 16 == 0,
+                    KVZ_EINVAL, "kvz_score_chunk: the appended K,V must be 16-byte aligned with strides that are multiples of 8 elements");
+        a.krep = app->k_state; a.krep_head_stride = app->ks_head_stride;
+        a.app_v = app->v_cache; a.vrep = app->v_state;
+        a.vrep_head_stride = app->vs_head_stride; a.vrep_row_stride = app->vs_row_stride;
+    }
     a.dq = make_fastdiv(q_len);
     a.dh = make_fastdiv(Hkv);
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
@@ -1727,14 +1626,6 @@ extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtyp
     return KVZ_OK;
 }
 
-#if KVZ_TRACE
-extern "C" int kvz_debug_read_trace2(unsigned long long* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace2), bytes);
-}
-extern "C" int kvz_debug_read_trace_b(unsigned long long* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kvz::g_trace_b), bytes);
-}
-#endif
 
 // test hook (host only, no GPU needed): the static partition of pass A for a geometry.  unit / tile: 257 entries each.
 extern "C" int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* unit, uint16_t* tile, int* n_blocks,

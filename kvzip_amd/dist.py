@@ -35,9 +35,11 @@ def unpack_record(rec: torch.Tensor, layers: int, Hkv: int) -> Dict:
 
 
 def gather_results(records: Sequence[torch.Tensor], n_contexts: int, layers: int, Hkv: int,
-                   group: Optional[dist.ProcessGroup] = None) -> List[Dict]:
+                   group: Optional[dist.ProcessGroup] = None, force_collective: bool = False) -> List[Dict]:
     """Every rank contributes the records of the contexts it owns (``shard_contexts`` order); every rank gets
-    the full list back in context order.  One all_gather of ``ceil(n_contexts/world)`` fixed-size slots."""
+    the full list back in context order.  One all_gather of ``ceil(n_contexts/world)`` fixed-size slots.
+    ``force_collective``: issue the all_gather even in a process group of ONE rank (a 1-GPU box still exercises RCCL:
+    ``bench.py --force-dist``, ``tests/test_gpu_rccl.py``)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_contexts(n_contexts, rank, world)
@@ -48,7 +50,7 @@ def gather_results(records: Sequence[torch.Tensor], n_contexts: int, layers: int
     buf = torch.full((slots, width), float("nan"), dtype=torch.float64, device=dev)
     for i, r in enumerate(records):
         buf[i] = r
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         gathered = [buf]
     else:
         gathered = [torch.empty_like(buf) for _ in range(world)]
@@ -58,3 +60,12 @@ def gather_results(records: Sequence[torch.Tensor], n_contexts: int, layers: int
         for i, ctx in enumerate(shard_contexts(n_contexts, rk, world)):
             out[ctx] = unpack_record(gathered[rk][i], layers, Hkv)
     return out
+
+
+def backend_version() -> str:
+    """``"rccl x.y.z"`` of the collective library behind torch.distributed's "nccl" backend on ROCm ("" without a GPU build)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return "rccl " + ".".join(str(x) for x in (v if isinstance(v, tuple) else (v,)))
+    except Exception:  # CPU-only build / no nccl module
+        return ""

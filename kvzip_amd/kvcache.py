@@ -66,7 +66,12 @@ class _CacheBase(KVScore):
         self._pend_app = None                    # append left by update() for the fused update + score call of _get_score
         # scoring pass: update() leaves its append to the _get_score() call that follows it (attention/attn.py:44-54) and the two
         # become ONE library call.  Between the two calls the returned K,V views do not hold the new rows yet, so this is opt-in:
-        # kvzip_amd.attn (the forward pass this package owns) and ModelKVzip.scoring switch it on
+        # kvzip_amd.attn (the forward pass this package owns) and ModelKVzip.scoring switch it on (True: the append is a launch on
+        # the caller's stream, where the forward's own attention reads the rows next).  "kernel": no append launch at all - the
+        # row-statistics kernel stages the chunk's K rows from key_states and writes K and V into the cache itself, on the scoring
+        # side stream; for drivers whose stream does not read the chunk's rows back from the cache before slice() (they own the repeat
+        # pass's Q/K/V: bench.py, a serving engine that scores from its own KV pages); every reader inside this class orders itself
+        # behind the scoring call (_wait_score)
         self.fuse_update_score = False
 
     # -- dense (pre-prune) storage --------------------------------------------------------------
@@ -479,7 +484,7 @@ class EvictCache(_CacheBase):
             self._dyn_off = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._sync_dyn(offsets0[0])   # the WHOLE count lives on the device from here on: the captured host part is 0
         out = torch.empty((L, self.n_heads_kv, self.n_group_kv, query.shape[-1]), dtype=query.dtype, device=query.device)
-        self._attn_workspace(1, query.shape[-1], query.device)
+        ws = self._attn_workspace(1, query.shape[-1], query.device)
         dyn0 = self._dyn_val
         torch.cuda.synchronize(query.device)
         graph = torch.cuda.CUDAGraph()
@@ -489,7 +494,12 @@ class EvictCache(_CacheBase):
             ops.check(lib.kvz_add_i32(self._dyn_off.data_ptr(), 1, ops._stream(self._dyn_off)), "kvz_add_i32")
         # (capturing executes nothing: the host bookkeeping goes back to where it was)
         self.info["offset"], self._seen_tokens, self._dyn_val = offsets0, seen0, dyn0
-        return DecodeGraph(self, graph, out)
+        # the captured kernels hold RAW ADDRESSES: the graph object keeps every tensor behind them alive (the shared attention
+        # workspace may be dropped from the cache's own table by later calls with other query lengths, the static input buffers
+        # belong to the caller)
+        pinned = (ws, self._dyn_off, query, key, value, list(self.key_cache), list(self.value_cache),
+                  list(self.info["seg_start"]), list(self.info["len_k"]))
+        return DecodeGraph(self, graph, out, pinned)
 
     def _sync_dyn(self, value: int):
         """device part of the appended-token count := value (one fill on the current stream)"""
@@ -501,9 +511,10 @@ class EvictCache(_CacheBase):
 class DecodeGraph:
     """One captured generation step of an ``EvictCache`` (see ``EvictCache.decode_graph``)."""
 
-    def __init__(self, kv: "EvictCache", graph, out: torch.Tensor):
+    def __init__(self, kv: "EvictCache", graph, out: torch.Tensor, pinned=()):
         self.kv, self.graph, self.out = kv, graph, out
         self.epoch = kv._layout_epoch
+        self._pinned = pinned   # every tensor whose address a captured kernel holds (see decode_graph)
 
     def replay(self) -> torch.Tensor:
         kv = self.kv

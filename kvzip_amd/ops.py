@@ -6,6 +6,7 @@ Every function takes CUDA(=HIP) tensors, passes raw ``data_ptr()`` values plus t
 from __future__ import annotations
 
 import math
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -26,30 +27,35 @@ def _dtype_code(dtype: torch.dtype) -> int:
                    "(reference csrc/csrc/static_switch.h:3-12)")
 
 
+_tls = threading.local()  # .restore: device that was current before a call had to switch (given back by check() after the launch)
+
+
+def _give_back_device() -> None:
+    prev = getattr(_tls, "restore", None)
+    if prev is not None:
+        _tls.restore = None
+        torch.cuda.set_device(prev)
+
+
 def check(rc: int, who: str) -> None:
     """Raise on a non-zero return code; give the caller back the current device it had before the call (see ``_stream``)."""
-    global _restore_device
-    if _restore_device is not None:
-        prev, _restore_device = _restore_device, None
-        torch.cuda.set_device(prev)
+    _give_back_device()
     _check(rc, who)
-
-
-_restore_device = None  # device that was current before a call had to switch (restored by check() after the launch)
 
 
 def _stream(t: torch.Tensor) -> int:
     """HIP stream handle for a launch on ``t``'s device.  The library launches on the CURRENT HIP device, so a tensor that
     lives on another GPU (a cache on cuda:1 while cuda:0 is current) makes its device current for the call; ``check`` - which
-    follows every launch - switches back, so the caller's current device is what it was.  Every cache object and every call of
-    this module works on ONE device (all tensors of a call must share it)."""
-    global _restore_device
+    follows every launch - switches back, so the caller's current device is what it was.  The pending switch is per host thread,
+    and a switch that a failed call left behind (an exception between ``_stream`` and ``check``) is undone by the next call
+    before it looks at the current device.  Every cache object and every call of this module works on ONE device (all tensors
+    of a call must share it)."""
     if not t.is_cuda:
         raise KvzError("the HIP path needs device tensors (no CPU fallback)")
+    _give_back_device()
     cur = torch.cuda.current_device()
     if t.device.index != cur:
-        if _restore_device is None:
-            _restore_device = cur
+        _tls.restore = cur
         torch.cuda.set_device(t.device)
     return raw_stream(t.device.index)
 

@@ -224,6 +224,21 @@ class KVScore:
         self._score_buf = new
         self._score_log = self._new_score_log(need)
 
+    def _check_device(self, dev, layer_idx: int):
+        """A cache object (side streams, events, workspaces) works on ONE device, and the library launches on the CURRENT HIP
+        device: both scoring entries (``_get_score``, ``_score_forward``) refuse anything else instead of launching on the wrong GPU
+        (``ModelKVzip`` makes the model's device current around its forward passes)."""
+        di = self._dev_idx
+        if di is None:  # (resolved once: the cache object lives on ONE device)
+            d0 = torch.device(self.device)
+            di = self._dev_idx = d0.index if d0.index is not None else dev.index
+        if dev.index != di:
+            raise ops.KvzError(f"layer {layer_idx} lives on {dev}, the cache on {self.device}: a cache object (side streams, events, "
+                               "workspaces) works on ONE device - load the model on one GPU (one context per GPU is the multi-GPU scheme)")
+        if di != torch.cuda.current_device():
+            raise ops.KvzError(f"the cache lives on {dev} but cuda:{torch.cuda.current_device()} is current: wrap the forward pass in "
+                               f"`with torch.cuda.device({dev.index}):` (the library launches on the current HIP device)")
+
     # reference: attention/score.py:36-65
     def _get_score(self, query_states: torch.Tensor, key_states: torch.Tensor, layer_idx: int):
         """query ``[1, H, q, D]``, key ``[1, Hkv, klen, D]`` (cache ++ repeat chunk).  Writes the chunk's
@@ -243,16 +258,7 @@ class KVScore:
         assert bsz == 1 and query_states.stride(3) == 1 and query_states.stride(2) == D
         assert key_states.stride(3) == 1 and key_states.stride(2) == D and key_states.dtype == query_states.dtype
         dev = query_states.device
-        di = self._dev_idx
-        if di is None:  # (resolved once: the cache object lives on ONE device)
-            d0 = torch.device(self.device)
-            di = self._dev_idx = d0.index if d0.index is not None else dev.index
-        if dev.index != di:
-            raise ops.KvzError(f"layer {layer_idx} lives on {dev}, the cache on {self.device}: a cache object (side streams, events, "
-                               "workspaces) works on ONE device - load the model on one GPU (one context per GPU is the multi-GPU scheme)")
-        if di != torch.cuda.current_device():
-            raise ops.KvzError(f"the cache lives on {dev} but cuda:{torch.cuda.current_device()} is current: wrap the forward pass in "
-                               f"`with torch.cuda.device({dev.index}):` (the library launches on the current HIP device)")
+        self._check_device(dev, layer_idx)
         need = self._ws_need.get((q_len, m, H))
         if need is None:
             need = self._ws_need[(q_len, m, H)] = lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, self.sink)
@@ -294,11 +300,18 @@ class KVScore:
             _, ks, vs, fill = pend
             sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
             out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
+            in_kernel = 1 if self.fuse_update_score == "kernel" else 0
+            if in_kernel and nstreams > 1:
+                ks.record_stream(st)   # the side stream reads the chunk's K,V itself (pass A stages / copies them)
+                vs.record_stream(st)
             rc = lib.kvz_update_score_async_log(self._async, layer_idx, cur, side, sk.data_ptr(), sv.data_ptr(), sk.stride(1), fill,
                                                 ks.data_ptr(), vs.data_ptr(), ks.stride(1), ks.stride(2), vs.stride(1), vs.stride(2),
                                                 ks.shape[-2], query_states.data_ptr(), query_states.stride(1), self.sink,
                                                 self.start_idx, self.end_idx, q_len, Hkv, H // Hkv, D,
-                                                ops._dtype_code(query_states.dtype), out_ptr, n_tot, ws.data_ptr(), ws.numel())
+                                                ops._dtype_code(query_states.dtype), out_ptr, n_tot, ws.data_ptr(), ws.numel(),
+                                                in_kernel)
+            if in_kernel:
+                self._pending = True   # (also on one stream: readers of the cache rows go through _wait_score)
             self._log_dirty = True
         elif log is not None and log.shape[-1] == n_tot:
             # deferred path: pass B merges its row slices by atomics into the log buffer, the finalize launch happens once, when
@@ -343,6 +356,7 @@ class KVScore:
         if getattr(self, "_pend_app", None) is not None:
             self._flush_append()  # the forward reads the rows of the repeat chunk
         dev = query_states.device
+        self._check_device(dev, layer_idx)
         R = (H // Hkv) * q_len
         stride = (R + 127) // 128 * 128
         while len(self._win_stats) <= layer_idx:

@@ -56,6 +56,21 @@ def load_head_score(model_name: str, ctx_len: int, head_score_dir: str, device) 
     return attn.unsqueeze(-1).expand(-1, -1, ctx_len).unsqueeze(1)
 
 
+def _on_model_device(fn):
+    """Run a ModelKVzip method with the model's GPU as the current device: the library launches on the CURRENT HIP device, and a
+    model that lives on cuda:1 while cuda:0 is current must work the same way (side streams, events, workspaces of the cache)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = self.device
+        if dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class ModelKVzip:
 
     def __init__(self, model: Union[str, torch.nn.Module], kv_type: str = "evict", tokenizer=None,
@@ -125,6 +140,7 @@ class ModelKVzip:
         return torch.cat([q_ids, self.postfix_ids], dim=1)
 
     # ---- forward (reference model/wrapper.py:120-146) ---------------------------------------------------------
+    @_on_model_device
     @torch.inference_mode()
     def __call__(self, input_ids: torch.Tensor, kv, update_cache: bool = False, return_logits: bool = False,
                  *args, **kwargs):
@@ -151,6 +167,7 @@ class ModelKVzip:
         return kv
 
     # ---- prefill + scoring (reference model/wrapper.py:169-249) ------------------------------------------------
+    @_on_model_device
     @torch.inference_mode()
     def prefill(self, ctx_ids: Union[str, torch.Tensor], prefill_chunk_size: int = 16000, load_score: bool = False,
                 do_score: bool = True):
@@ -187,32 +204,40 @@ class ModelKVzip:
             inputs.append((a_ids, torch.cat([q_ids, self.postfix_ids, a_ids], dim=1)))
         return inputs
 
+    @_on_model_device
     @torch.inference_mode()
     def scoring(self, kv, ctx_ids: torch.Tensor, load_score: bool = False, chunk_size: int = 2000,
                 repeat_prompt_ids=None):
         """KV importance scoring (fills ``kv.score``)."""
         if not load_score:
             kv.init_score()
-            if hasattr(kv, "fuse_update_score"):
+            fused = hasattr(kv, "fuse_update_score")
+            if fused:
                 kv.fuse_update_score = True  # the forward pass is kvzip_amd.attn: update() is always followed by _get_score()
                 kv.fuse_forward_score = self.fuse_forward_score  # ... and its attention kernel emits the row statistics (f2)
             start_idx_tmp = kv.start_idx
             kv.end_idx = 0
-            for prefill_ids_p, repeat_ids_p in self.self_task(ctx_ids, chunk_size=chunk_size,
-                                                              repeat_prompt_ids=repeat_prompt_ids):
-                kv.end_idx = kv.start_idx + prefill_ids_p.shape[1]      # window of this chunk
-                self.__call__(repeat_ids_p, kv, update_cache=False)     # the patched attention calls kv._get_score
-                kv.start_idx = kv.end_idx
-            kv.start_idx = start_idx_tmp
+            try:
+                for prefill_ids_p, repeat_ids_p in self.self_task(ctx_ids, chunk_size=chunk_size,
+                                                                  repeat_prompt_ids=repeat_prompt_ids):
+                    kv.end_idx = kv.start_idx + prefill_ids_p.shape[1]      # window of this chunk
+                    self.__call__(repeat_ids_p, kv, update_cache=False)     # the patched attention calls kv._get_score
+                    kv.start_idx = kv.end_idx
+            finally:
+                # also when a forward pass raised (out of memory ...): the cache must not stay in the mode in which update()
+                # returns views whose new rows are still to be written, nor keep the chunk's K,V pinned
+                kv.start_idx = start_idx_tmp
+                if fused:
+                    kv.fuse_update_score = False
+                    kv.fuse_forward_score = False
+                    kv._flush_append()
             assert kv.score[0].shape[-1] == kv.ctx_len
         else:
             kv.score = load_head_score(self.name, kv.ctx_len, self.head_score_dir, self.device)
         kv.get_score = False
-        if hasattr(kv, "fuse_update_score"):
-            kv.fuse_update_score = False
-            kv.fuse_forward_score = False
 
     # ---- generation (reference model/wrapper.py:251-284) ---------------------------------------------------------
+    @_on_model_device
     @torch.inference_mode()
     def generate(self, query: Union[str, torch.Tensor], kv=None, update_cache: bool = False,
                  return_ids: bool = False):
@@ -269,6 +294,7 @@ class ModelKVzip:
             out.append(([ratio, round(ratio_true, 4), round(thres, 4)], fn(kv)))
         return out
 
+    @_on_model_device
     @torch.inference_mode()
     def _prob(self, input_ids: torch.Tensor, kv=None, device: str = "cuda") -> torch.Tensor:
         """Next-token probabilities (reference model/wrapper.py:286-306)."""

@@ -104,3 +104,33 @@ def test_bench_ranks_rejects_wrong_world(monkeypatch):
         bench.Ranks(2, "gloo")
     args = bench.parse(["--level", "head"])
     assert args.ratio == 0.6 and bench.parse([]).ratio == 0.3
+
+
+def _forced_world1_entry(out_path):
+    """`bench.py --force-dist` on one rank: the process group exists, the gather and the max reduction go through it."""
+    import json
+    import bench
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        os.environ.pop(var, None)
+    ranks = bench.Ranks(1, "gloo", force=True)
+    assert ranks.forced and ranks.dist is not None and ranks.dist.get_world_size() == 1
+    ranks.barrier()
+    len_k = torch.full((3, 2), 777, dtype=torch.int32)
+    recs = ranks.gather_records(0.125, 0.3, len_k, 3, 2)
+    t = ranks.max_over_ranks(1.5)
+    ranks.close()
+    with open(out_path, "w") as f:
+        json.dump({"thres": recs[0]["thres"], "n_kept": recs[0]["n_kept"], "t": t, "n": len(recs)}, f)
+
+
+def test_bench_force_dist_world1_gloo(tmp_path):
+    """The forced single-rank process group (what tests/test_gpu_rccl.py runs over RCCL on the GPU box), here over gloo."""
+    import json
+    out = str(tmp_path / "forced.json")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_forced_world1_entry, args=(out,))
+    p.start()
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    d = json.load(open(out))
+    assert d == {"thres": 0.125, "n_kept": 3 * 2 * 777, "t": 1.5, "n": 1}
