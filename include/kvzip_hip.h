@@ -121,6 +121,11 @@ int kvz_score_from_stats_async_log(int handle, int slot, kvz_stream_t caller, kv
                                    uint32_t* log_out, int64_t log_head_stride);
 int kvz_score_log_fill(uint32_t* log, int64_t n, kvz_stream_t stream);
 int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype, kvz_stream_t stream);
+/* kvz_score_finalize_log AND the first pass of kvz_select_threshold in one launch: select_ws (kvz_select_workspace_bytes() bytes) is
+ * cleared and receives the histogram of the top 11 bits of the order key of every entry of `out` as it stands afterwards (entries
+ * never scored contribute the value `out` already holds).  Follow with kvz_select_threshold_prehist on exactly these n values. */
+int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void* out, int dtype, void* select_ws, size_t select_ws_bytes,
+                                kvz_stream_t stream);
 
 /* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78)
  * followed by kvz_score_chunk_async_log on the side stream with k = k_cache, klen = fill + t.
@@ -162,6 +167,13 @@ int kvz_select_threshold(const void* scores, int64_t n, double ratio, int dtype,
                          int64_t row_len, int32_t* row_counts,
                          float* thres_dev, int64_t* kept_dev,
                          void* ws, size_t ws_bytes, kvz_stream_t stream);
+/* The same selection when `ws` already holds the first histogram of exactly these scores (kvz_score_finalize_log_hist): two launches
+ * (low-bits histogram, mask) instead of three.  Same results, bit for bit. */
+int kvz_select_threshold_prehist(const void* scores, int64_t n, double ratio, int dtype,
+                                 uint8_t* valid_out,
+                                 int64_t row_len, int32_t* row_counts,
+                                 float* thres_dev, int64_t* kept_dev,
+                                 void* ws, size_t ws_bytes, kvz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * a5  per-(layer,head) top-k         reference: attention/score.py:104-120

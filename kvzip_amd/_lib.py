@@ -42,6 +42,7 @@ SIGNATURES = {
                                   _i64, _vp]),
     "kvz_score_log_fill": (_i, [_vp, _i64, _vp]),
     "kvz_score_finalize_log": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "kvz_score_finalize_log_hist": (_i, [_vp, _i64, _vp, _i, _vp, _sz, _vp]),
     "kvz_dense_append": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_debug_fastdiv": (_i, [_i, _i, _vp, _vp]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "kvz_debug_score_plan": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvz_select_threshold_prehist": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvz_select_topk_rows": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
     "kvz_select_heads": (_i, [_vp, _i, _i64, _d, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_rowmax16": (_i, [_vp, _i64, _i64, _i, _vp, _vp]),

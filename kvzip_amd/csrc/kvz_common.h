@@ -69,6 +69,11 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
                float* lse_out, hipStream_t stream, int win_sink = 0, int win_start = 0, int win_end = 0, float* win_stats = nullptr,
                int64_t win_stats_head_stride = 0);
 
+// selection workspace shared by kvz_select.hip and the fused finalize + histogram launch of kvz_score.hip (uint32 words):
+// [0, 2048) histogram of the top 11 bits of the order key, [2048, 2080) histogram of the low 5 bits inside the picked bin, 4 spare
+constexpr int SEL_HI_BINS = 2048, SEL_LO_BINS = 32;
+constexpr size_t SEL_WS_WORDS = SEL_HI_BINS + SEL_LO_BINS + 4;
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- half / bf16 bit helpers ------------------------------------------------------------

@@ -1280,6 +1280,54 @@ __global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int6
     if (b != SC_LOG_EMPTY) out[i] = (T)(b == 0u ? __builtin_nanf("") : expf(__builtin_bit_cast(float, b)));  // 0 = NaN (see pass B)
 }
 
+// the same launch, and the histogram of the top 11 bits of the order key of EVERY entry of `out` as it stands afterwards (entries
+// never scored contribute the value `out` already holds): the first pass of the global-threshold selection (kvz_select.hip) rides
+// on the launch that streams all scores anyway.  LDS-privatised histogram, one global atomic per non-empty bin and block.
+template <typename T>
+__global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint32_t* __restrict__ log, int64_t n, T* __restrict__ out,
+                                                                     uint32_t* __restrict__ hist_hi) {
+    __shared__ uint32_t lh[SEL_HI_BINS];
+    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    auto conv = [](uint32_t b) -> uint32_t { return bits16<T>((T)(b == 0u ? __builtin_nanf("") : expf(__builtin_bit_cast(float, b)))); };
+    const int64_t nvec = n >> 3;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 l0 = reinterpret_cast<const u32x4*>(log)[2 * i], l1 = reinterpret_cast<const u32x4*>(log)[2 * i + 1];
+        const uint32_t lw[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        bool any_empty = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) any_empty |= lw[j] == SC_LOG_EMPTY;
+        u32x4 o = {0, 0, 0, 0};
+        if (any_empty) o = reinterpret_cast<const u32x4*>(out)[i];  // (rare: a buffer that was not scored to the end)
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t old = (o[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+            v[j] = lw[j] == SC_LOG_EMPTY ? old : conv(lw[j]);
+            atomicAdd(&lh[order_key16(v[j]) >> 5], 1u);
+        }
+        const u32x4 w = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+        reinterpret_cast<u32x4*>(out)[i] = w;
+    }
+    if (blockIdx.x == 0) {  // tail (< 8 elements)
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 256) {
+            const uint32_t b = log[i];
+            uint32_t v = bits16<T>(out[i]);
+            if (b != SC_LOG_EMPTY) {
+                v = conv(b);
+                reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)v;
+            }
+            atomicAdd(&lh[order_key16(v) >> 5], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 256) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&hist_hi[i], c);
+    }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // number of row slices of pass B: enough blocks to fill 256 CUs once, no empty slice, and a slice's merged statistics fit LDS
@@ -1527,6 +1575,27 @@ extern "C" int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out,
     if (dtype == KVZ_F16) hipLaunchKernelGGL((score_finalize_log_kernel<_Float16>), grid, block, 0, stream, log, n, reinterpret_cast<_Float16*>(out));
     else hipLaunchKernelGGL((score_finalize_log_kernel<__bf16>), grid, block, 0, stream, log, n, reinterpret_cast<__bf16*>(out));
     KVZ_CHECK_LAUNCH("score_finalize_log_kernel");
+    return KVZ_OK;
+}
+
+extern "C" int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void* out, int dtype, void* select_ws, size_t select_ws_bytes,
+                                           kvz_stream_t stream_) {
+    KVZ_REQUIRE(log && out && select_ws && n > 0, KVZ_EINVAL, "kvz_score_finalize_log_hist: bad arguments");
+    KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_score_finalize_log_hist: bad dtype %d", dtype);
+    KVZ_REQUIRE(select_ws_bytes >= SEL_WS_WORDS * sizeof(uint32_t) && (reinterpret_cast<uintptr_t>(select_ws) & 3u) == 0, KVZ_EWORKSPACE,
+                "kvz_score_finalize_log_hist: selection workspace too small (kvz_select_workspace_bytes)");
+    KVZ_REQUIRE(aligned16(log) && aligned16(out), KVZ_EINVAL, "kvz_score_finalize_log_hist: log / out must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    KVZ_REQUIRE(hipMemsetAsync(select_ws, 0, SEL_WS_WORDS * sizeof(uint32_t), stream) == hipSuccess, KVZ_ELAUNCH,
+                "kvz_score_finalize_log_hist: hipMemsetAsync failed");
+    int blocks = (int)(((n + 7) / 8 + 255) / 256);
+    if (blocks > 512) blocks = 512;  // 2 per CU: every block flushes its non-empty bins with global atomics
+    if (blocks < 1) blocks = 1;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(select_ws);
+    ProfScope ps("score_finalize_log", stream);
+    if (dtype == KVZ_F16) hipLaunchKernelGGL((score_finalize_log_hist_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, log, n, reinterpret_cast<_Float16*>(out), hist);
+    else hipLaunchKernelGGL((score_finalize_log_hist_kernel<__bf16>), dim3(blocks), dim3(256), 0, stream, log, n, reinterpret_cast<__bf16*>(out), hist);
+    KVZ_CHECK_LAUNCH("score_finalize_log_hist_kernel");
     return KVZ_OK;
 }
 

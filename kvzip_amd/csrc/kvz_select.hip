@@ -5,17 +5,21 @@
 // (attention/score.py:104-120).  Scores are fp16/bf16, i.e. 16-bit patterns, so the k-th largest
 // value is found exactly with a two-level radix histogram (11 + 5 bits) in two streaming reads,
 // followed by one streaming read that emits the boolean mask.  HBM-bound: 5 B per score.
+// Round 4: THREE launches (histogram of the top bits; histogram of the low bits; mask) - every block of the second and third
+// launch locates the bin itself from the global histogram of the launch before (2048 + 32 counters: a few hundred cycles)
+// instead of waiting for a one-block "pick" launch, and the second launch also clears the counters the third one adds to.
+// When the scores come out of the deferred scoring path the first histogram rides in the launch that turns the log buffer into
+// 16-bit scores (kvz_score_finalize_log_hist, kvz_score.hip), which streams every score anyway: two launches here.
 //
-// Workspace layout (uint32 words):  [0,2048) hist_hi   [2048,2080) hist_lo   [2080] picked top bin   [2081] 16-bit key of the
-// threshold   [2082,2084) residual rank inside the top bin (uint64)
+// Workspace layout (uint32 words):  [0,2048) hist_hi   [2048,2080) hist_lo   [2080,2084) unused
 #include "kvz_common.h"
 
 namespace kvz {
 
-constexpr int HI_BINS = 2048;  // top 11 bits of the order key
-constexpr int LO_BINS = 32;    // low 5 bits
+constexpr int HI_BINS = SEL_HI_BINS;  // top 11 bits of the order key
+constexpr int LO_BINS = SEL_LO_BINS;  // low 5 bits
 constexpr int SEL_THREADS = 256;
-constexpr size_t SELECT_WS_WORDS = HI_BINS + LO_BINS + 4;
+constexpr size_t SELECT_WS_WORDS = SEL_WS_WORDS;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -113,32 +117,20 @@ __device__ static inline void find_bin_desc(const uint32_t* hist, uint64_t idx, 
     __syncthreads();
 }
 
-// ---- pass 2: histogram of the low 5 bits inside the selected top bin -----------------------
-// one block: locate the top bin that contains rank idx (the per-block search used to cost more than the streaming)
-__global__ __launch_bounds__(SEL_THREADS) void select_pick_hi_kernel(const uint32_t* __restrict__ hist_hi, uint64_t idx,
-                                                                    uint32_t* __restrict__ picked) {
+// ---- pass 2: histogram of the low 5 bits inside the top bin that holds rank idx (every block finds that bin itself) -----------
+__global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores, int64_t n, uint64_t idx,
+                                                                    const uint32_t* __restrict__ hist_hi,
+                                                                    uint32_t* __restrict__ hist_lo, int32_t* __restrict__ row_counts,
+                                                                    int64_t rows, unsigned long long* __restrict__ kept_dev) {
+    __shared__ uint32_t ll[LO_BINS];
     uint32_t bin;
     uint64_t rank, above;
     find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
-    if (threadIdx.x == 0) {
-        picked[0] = bin;
-        *reinterpret_cast<uint64_t*>(picked + 2) = rank;
-    }
-}
-__global__ __launch_bounds__(SEL_THREADS) void select_pick_lo_kernel(const uint32_t* __restrict__ hist_lo,
-                                                                    uint32_t* __restrict__ picked) {
-    uint32_t lo;
-    uint64_t rank2, above2;
-    find_bin_desc<LO_BINS>(hist_lo, *reinterpret_cast<const uint64_t*>(picked + 2), &lo, &rank2, &above2);
-    if (threadIdx.x == 0) picked[1] = (picked[0] << 5) | lo;
-}
-
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores,
-                                                                    int64_t n, const uint32_t* __restrict__ picked,
-                                                                    uint32_t* __restrict__ hist_lo) {
-    __shared__ uint32_t ll[LO_BINS];
-    const uint32_t bin = picked[0];
     if (threadIdx.x < LO_BINS) ll[threadIdx.x] = 0;
+    // the counters the mask launch adds to (nothing else touches them before it)
+    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; row_counts && i < rows; i += (int64_t)gridDim.x * SEL_THREADS)
+        row_counts[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *kept_dev = 0ull;
     __syncthreads();
 
     const int64_t nvec = n >> 3;
@@ -171,10 +163,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
 // grid = (blocks_per_row, rows) when row_counts != nullptr, each block covering a slice of ONE row;
 // otherwise rows == 1 and row_len == n.
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
-    const uint16_t* __restrict__ scores, int64_t row_len, int dtype, const uint32_t* __restrict__ picked,
-    uint8_t* __restrict__ valid_out, int32_t* __restrict__ row_counts, float* __restrict__ thres_dev,
-    unsigned long long* __restrict__ kept_dev) {
-    const uint32_t tkey = picked[1];
+    const uint16_t* __restrict__ scores, int64_t row_len, int dtype, uint64_t idx, const uint32_t* __restrict__ hist_hi,
+    const uint32_t* __restrict__ hist_lo, uint8_t* __restrict__ valid_out, int32_t* __restrict__ row_counts,
+    float* __restrict__ thres_dev, unsigned long long* __restrict__ kept_dev) {
+    // the 16-bit key of the threshold: top bin from the first histogram, low bits from the second (every block, redundantly)
+    uint32_t bin, lo;
+    uint64_t rank, above, rank2, above2;
+    find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
+    find_bin_desc<LO_BINS>(hist_lo, rank, &lo, &rank2, &above2);
+    const uint32_t tkey = (bin << 5) | lo;
     const uint32_t tbits = order_key16_inv(tkey);
     const float thres = half_bits_to_float(tbits, dtype);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *thres_dev = thres;
@@ -429,9 +426,22 @@ using namespace kvz;
 
 extern "C" size_t kvz_select_workspace_bytes(void) { return SELECT_WS_WORDS * sizeof(uint32_t); }
 
+static int select_threshold_impl(const void* scores, int64_t n, double ratio, int dtype, uint8_t* valid_out,
+                                 int64_t row_len, int32_t* row_counts, float* thres_dev, int64_t* kept_dev,
+                                 void* ws, size_t ws_bytes, kvz_stream_t stream_, bool prehist);
 extern "C" int kvz_select_threshold(const void* scores, int64_t n, double ratio, int dtype, uint8_t* valid_out,
                                     int64_t row_len, int32_t* row_counts, float* thres_dev, int64_t* kept_dev,
                                     void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    return select_threshold_impl(scores, n, ratio, dtype, valid_out, row_len, row_counts, thres_dev, kept_dev, ws, ws_bytes, stream_, false);
+}
+extern "C" int kvz_select_threshold_prehist(const void* scores, int64_t n, double ratio, int dtype, uint8_t* valid_out,
+                                            int64_t row_len, int32_t* row_counts, float* thres_dev, int64_t* kept_dev,
+                                            void* ws, size_t ws_bytes, kvz_stream_t stream_) {
+    return select_threshold_impl(scores, n, ratio, dtype, valid_out, row_len, row_counts, thres_dev, kept_dev, ws, ws_bytes, stream_, true);
+}
+static int select_threshold_impl(const void* scores, int64_t n, double ratio, int dtype, uint8_t* valid_out,
+                                 int64_t row_len, int32_t* row_counts, float* thres_dev, int64_t* kept_dev,
+                                 void* ws, size_t ws_bytes, kvz_stream_t stream_, bool prehist) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(scores && valid_out && thres_dev && kept_dev && ws, KVZ_EINVAL, "kvz_select_threshold: null pointer");
     KVZ_REQUIRE(n > 0, KVZ_EINVAL, "kvz_select_threshold: n must be > 0 (got %lld)", (long long)n);
@@ -462,23 +472,22 @@ extern "C" int kvz_select_threshold(const void* scores, int64_t n, double ratio,
 
     uint32_t* hist_hi = reinterpret_cast<uint32_t*>(ws);
     uint32_t* hist_lo = hist_hi + HI_BINS;
-    (void)hipMemsetAsync(ws, 0, SELECT_WS_WORDS * sizeof(uint32_t), stream);
-    (void)hipMemsetAsync(kept_dev, 0, sizeof(int64_t), stream);
-    if (row_counts) (void)hipMemsetAsync(row_counts, 0, (size_t)rows * sizeof(int32_t), stream);
+    // prehist: hist_hi already holds the histogram of exactly these scores and hist_lo is zero (kvz_score_finalize_log_hist)
+    if (!prehist) (void)hipMemsetAsync(ws, 0, SELECT_WS_WORDS * sizeof(uint32_t), stream);
 
     const int64_t nvec = (n + 7) >> 3;
     int blocks = (int)((nvec + SEL_THREADS - 1) / SEL_THREADS);
     if (blocks > 512) blocks = 512;  // 2 per CU: every block flushes its non-empty bins with global atomics
     if (blocks < 1) blocks = 1;
-    uint32_t* picked = hist_lo + LO_BINS;
     const uint16_t* s16 = reinterpret_cast<const uint16_t*>(scores);
-    ProfScope ps("select", stream);  // the three streaming passes
-    hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, hist_hi);
-    KVZ_CHECK_LAUNCH("select_hist_hi_kernel");
-    hipLaunchKernelGGL(select_pick_hi_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, hist_hi, (uint64_t)idx, picked);
-    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, picked, hist_lo);
+    ProfScope ps("select", stream);  // the streaming passes
+    if (!prehist) {
+        hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, hist_hi);
+        KVZ_CHECK_LAUNCH("select_hist_hi_kernel");
+    }
+    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, (uint64_t)idx, hist_hi, hist_lo,
+                       row_counts, rows, reinterpret_cast<unsigned long long*>(kept_dev));
     KVZ_CHECK_LAUNCH("select_hist_lo_kernel");
-    hipLaunchKernelGGL(select_pick_lo_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, hist_lo, picked);
 
     // rows whose start is not 16-byte aligned take the scalar path inside the kernel (row_len % 8 != 0)
     const int64_t per_row_vec = ((row_len & 7) == 0) ? (row_len >> 3) : row_len;
@@ -488,7 +497,8 @@ extern "C" int kvz_select_threshold(const void* scores, int64_t n, double ratio,
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(select_emit_kernel, dim3(bx, (unsigned)rows), dim3(SEL_THREADS), 0, stream, s16, row_len, dtype,
-                       picked, valid_out, row_counts, thres_dev, reinterpret_cast<unsigned long long*>(kept_dev));
+                       (uint64_t)idx, hist_hi, hist_lo, valid_out, row_counts, thres_dev,
+                       reinterpret_cast<unsigned long long*>(kept_dev));
     KVZ_CHECK_LAUNCH("select_emit_kernel");
     return KVZ_OK;
 }

@@ -211,8 +211,18 @@ class _CacheBase(KVScore):
             k = int(self.valid.shape[-1] * ratio) if ratio < 1 else self.valid.shape[-1]
             kept = k * (n // self.valid.shape[-1])
         else:
+            # scores still in the log buffer of the deferred scoring path: the launch that turns them into 16-bit values also
+            # produces the first histogram of the selection (it streams every score anyway)
+            hist = None
+            buf = self._score_buf
+            if (self._score is None and self._log_dirty and self._score_log is not None and buf is not None and buf.numel() > 0
+                    and ratio < 1 and all(f == buf.shape[-1] for f in self._score_fill)):
+                self._wait_score(finalize=False)
+                hist = ops.select_workspace(buf.device)
+                if not self._finalize_log(hist):
+                    hist = None
             score = self._stacked_score(self.score)
-            valid, thres_dev, kept_dev, _ = self._threshold_device(score, ratio)
+            valid, thres_dev, kept_dev, _ = self._threshold_device(score, ratio, prehist=hist if score is buf else None)
             self.valid = valid.view(score.shape)
             host = torch.stack([thres_dev.double().squeeze(0), kept_dev.double().squeeze(0)]).cpu()  # one D2H sync
             thres = float(host[0]) if ratio < 1 else 0.

@@ -131,14 +131,21 @@ def score_chunk(query_states: torch.Tensor, key_states: torch.Tensor, sink: int,
 # --------------------------------------------------------------------------------------------------
 # a4 / a5  selection
 # --------------------------------------------------------------------------------------------------
-def select_threshold(score: torch.Tensor, ratio: float, row_len: Optional[int] = None
+def select_workspace(device) -> torch.Tensor:
+    """Scratch of the global-threshold selection (two radix histograms); cleared by the library call that fills it."""
+    return torch.empty(_lib.load().kvz_select_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def select_threshold(score: torch.Tensor, ratio: float, row_len: Optional[int] = None, prehist: Optional[torch.Tensor] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Global-threshold selection (reference attention/score.py:88-102) — device side only.
 
     Returns ``(valid bool like score, thres f32[1] (device), kept i64[1] (device), row_counts i32[rows] or None)``.
-    No host synchronisation happens here.
+    No host synchronisation happens here.  ``prehist``: a selection workspace that already holds the first histogram of exactly
+    these scores (``kvz_score_finalize_log_hist``, see ``KVScore._finalize_log``): one streaming pass less.
     """
     lib = _lib.load()
+    assert prehist is None or score.is_contiguous()
     score = score.contiguous()
     n = score.numel()
     dt = _dtype_code(score.dtype)
@@ -149,10 +156,10 @@ def select_threshold(score: torch.Tensor, ratio: float, row_len: Optional[int] =
     rows = None
     if row_len is not None:
         rows = torch.empty(n // row_len, dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.kvz_select_workspace_bytes(), dtype=torch.uint8, device=dev)
-    rc = lib.kvz_select_threshold(score.data_ptr(), n, float(ratio), dt, valid.data_ptr(),
-                                  row_len if row_len is not None else n, _ptr(rows), thres.data_ptr(),
-                                  kept.data_ptr(), ws.data_ptr(), ws.numel(), _stream(score))
+    ws = prehist if prehist is not None else select_workspace(dev)
+    fn = lib.kvz_select_threshold_prehist if (prehist is not None and ratio < 1) else lib.kvz_select_threshold
+    rc = fn(score.data_ptr(), n, float(ratio), dt, valid.data_ptr(), row_len if row_len is not None else n, _ptr(rows),
+            thres.data_ptr(), kept.data_ptr(), ws.data_ptr(), ws.numel(), _stream(score))
     check(rc, "kvz_select_threshold")
     return valid, thres, kept, rows
 

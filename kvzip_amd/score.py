@@ -158,14 +158,23 @@ class KVScore:
         if layer_idx is None and finalize and self._log_dirty:
             self._finalize_log()
 
-    def _finalize_log(self):
+    def _finalize_log(self, hist: Optional[torch.Tensor] = None) -> bool:
+        """Log buffer -> 16-bit scores (one launch for all layers and chunks).  ``hist``: a selection workspace that receives the
+        first histogram of the global-threshold selection in the same launch (the launch streams every score anyway).  Returns
+        True when the histogram was produced."""
         log, buf = self._score_log, self._score_buf
         self._log_dirty = False
         if log is None or buf is None or buf.numel() == 0:
-            return
+            return False
         lib = ops._lib.load()
+        if hist is not None:
+            rc = lib.kvz_score_finalize_log_hist(log.data_ptr(), log.numel(), buf.data_ptr(), ops._dtype_code(buf.dtype),
+                                                 hist.data_ptr(), hist.numel(), ops._stream(buf))
+            ops.check(rc, "kvz_score_finalize_log_hist")
+            return True
         rc = lib.kvz_score_finalize_log(log.data_ptr(), log.numel(), buf.data_ptr(), ops._dtype_code(buf.dtype), ops._stream(buf))
         ops.check(rc, "kvz_score_finalize_log")
+        return False
 
     def _new_score_log(self, n: int) -> Optional[torch.Tensor]:
         if not self.score_deferred or n == 0 or not torch.device(self.device).type == "cuda":
@@ -415,7 +424,7 @@ class KVScore:
         valid, thres, kept, rows = self._threshold_device(score, ratio)
         return valid.view(score.shape), thres.item() if ratio < 1 else 0.
 
-    def _threshold_device(self, score: torch.Tensor, ratio: float):
+    def _threshold_device(self, score: torch.Tensor, ratio: float, prehist: Optional[torch.Tensor] = None):
         """Device-side part of ``_threshold`` (no host sync): valid, thres[1], kept[1], row_counts[L*Hkv]."""
         if score.shape[-1] > 1 and score.stride(-1) == 0:
             # head-level scores expanded over the context (model/wrapper.py:56): select on the [L, Hkv] values themselves;
@@ -425,7 +434,7 @@ class KVScore:
             return valid_h.unsqueeze(-1).expand(score.shape), thres, kept, rows
         if not score.is_contiguous():
             score = score.contiguous()
-        return ops.select_threshold(score, ratio, row_len=score.shape[-1])
+        return ops.select_threshold(score, ratio, row_len=score.shape[-1], prehist=prehist if score.is_contiguous() else None)
 
     # reference: attention/score.py:104-120
     def _threshold_uniform(self, scores: Union[torch.Tensor, List[torch.Tensor]], ratio: float):

@@ -8,6 +8,9 @@ that a generator mismatch fails loudly instead of comparing different problems.
 import torch
 
 GEOM = dict(L=2, H=28, Hkv=4, D=128, sink=32, N=8000, chunk=2000)   # Qwen2.5-7B head geometry, 2 layers x 4 scoring chunks
+# round 4 (tests/golden/g10_e2e_d128_512k.npz): 8 layers x 8 scoring chunks = 512 000 scores under ONE global threshold
+GEOM_512K = dict(L=8, H=28, Hkv=4, D=128, sink=32, N=16000, chunk=2000)
+SEED_512K = 777
 
 
 def chunks(geom=GEOM):

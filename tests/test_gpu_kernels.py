@@ -59,6 +59,45 @@ def test_select_threshold_vs_oracle(dtype, shape):
         assert torch.equal(rows, want_v.view(-1, shape[-1]).sum(-1).int())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n_rows,row_len,holes", [(8, 4096, False), (6, 1000, True), (1, 13, True), (3, 2001, False)])
+def test_finalize_log_with_histogram_then_select(dtype, n_rows, row_len, holes):
+    """Round 4: ``kvz_score_finalize_log_hist`` (log buffer -> 16-bit scores AND the first histogram of the selection in one launch)
+    followed by ``kvz_select_threshold_prehist`` (two launches) against the plain finalize + three-launch selection and the oracle:
+    scores, masks, thresholds and counts bit-identical - also with entries that were never scored (they keep the value the score
+    buffer holds) and sizes that are not multiples of 8."""
+    o = ops()
+    lib = o._lib.load()
+    n = n_rows * row_len
+    g = torch.Generator().manual_seed(n + (7 if dtype == torch.bfloat16 else 0))
+    logs = -(torch.rand(n, generator=g) * 9.0)                       # log-scores (non-positive fp32)
+    logs[::17] = 0.0                                                  # score 1.0
+    log_bits = logs.view(torch.int32).clone()
+    log_bits[logs == 0.0] = 1                                         # (pass B's encoding of a value >= 0)
+    stale = (torch.rand(n, generator=g) ** 4).to(dtype)               # what the score buffer holds where nothing was scored
+    if holes:
+        empty = torch.rand(n, generator=g) < 0.2
+        log_bits[empty] = torch.tensor(0xFF800000 - (1 << 32), dtype=torch.int32)   # the fill pattern (-inf)
+    log_d = log_bits.to(DEV)
+    a, b = stale.clone().to(DEV), stale.clone().to(DEV)
+    st = o._stream(a)
+    o.check(lib.kvz_score_finalize_log(log_d.data_ptr(), n, a.data_ptr(), o._dtype_code(dtype), st), "finalize")
+    ws = o.select_workspace(DEV)
+    o.check(lib.kvz_score_finalize_log_hist(log_d.data_ptr(), n, b.data_ptr(), o._dtype_code(dtype), ws.data_ptr(), ws.numel(), st), "finalize_hist")
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    if holes:
+        assert torch.equal(a.cpu()[empty].view(torch.int16), stale[empty].view(torch.int16))
+    score = a.view(n_rows, 1, 1, row_len)
+    for ratio in (0.0, 0.05, 0.3, 0.6, 0.97):
+        o.check(lib.kvz_score_finalize_log_hist(log_d.data_ptr(), n, b.data_ptr(), o._dtype_code(dtype), ws.data_ptr(), ws.numel(), st), "finalize_hist")
+        v1, t1, k1, r1 = o.select_threshold(score, ratio, row_len=row_len)
+        v2, t2, k2, r2 = o.select_threshold(b.view(score.shape), ratio, row_len=row_len, prehist=ws)
+        want_v, want_t = orc.threshold(score.cpu(), ratio)
+        assert torch.equal(v1, v2) and torch.equal(v1.cpu(), want_v), (ratio,)
+        assert float(t1.item()) == float(t2.item()) == want_t
+        assert int(k1.item()) == int(k2.item()) == int(want_v.sum()) and torch.equal(r1, r2)
+
+
 def test_select_threshold_signs_and_zeros():
     score = torch.tensor([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.0, 65504.0, -65504.0, 6e-8, -6e-8, 0.0],
                          dtype=torch.float16).view(1, 1, 1, -1)
@@ -566,6 +605,33 @@ def test_varlen_attn_long_ragged_vs_oracle(q_len):
     assert (got - want).abs().max() <= 1e-3
 
 
+def test_decode_attn_margin_over_seeds():
+    """Round 4: the achieved error of the DECODE call (q_len = 1) against the oracle over 24 seeds and
+    ragged head lengths, next to north_star's 1e-3 (fp16) - printed and recorded as a distribution, so that the margin of the
+    bound is a number and not one lucky seed.  Short heads (a few keys) are where single outputs are largest."""
+    Hkv, G, D = 4, 7, 128
+    worst = []
+    for seed in range(24):
+        g = torch.Generator().manual_seed(1000 + seed)
+        lens = [int(x) for x in torch.randint(1, 6000, (Hkv,), generator=g)]
+        if seed % 4 == 0:
+            lens[seed % Hkv] = 1 + seed % 7          # a head with a handful of keys
+        starts, tot = [], 0
+        for ln in lens:
+            starts.append(tot)
+            tot += ln + 5
+        q = torch.randn(Hkv, G, D, generator=g).half()
+        k = torch.randn(tot, D, generator=g).half()
+        v = torch.randn(tot, D, generator=g).half()
+        want = orc.varlen_attn(q, k, v, starts, lens, 1).float()
+        got = ops().varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), torch.tensor(starts, dtype=torch.int32, device=DEV),
+                                torch.tensor(lens, dtype=torch.int32, device=DEV), 1, max(lens)).cpu().float()
+        worst.append(float((got - want).abs().max()))
+        check_attn(f"decode_margin/seed{seed}", got, want, 1e-3, ulp_of=torch.float16)
+    w = sorted(worst)
+    print(f"\nDECODE MARGIN over {len(w)} seeds: max |err| min {w[0]:.2e} median {w[len(w) // 2]:.2e} max {w[-1]:.2e} (bound 1e-3)")
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
     """The one-launch attention: work items cut from the SUM of very ragged head lengths (AdaKV-style budgets, a dropped head,
@@ -628,12 +694,12 @@ def test_varlen_attn_many_query_rows_ragged_on_the_32_row_kernel(q_len, dtype):
     want = orc.varlen_attn(q, k, v, starts, lens, q_len).float()
     ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
     kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
-    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
     prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
     try:
         for meta in (None, ops._meta_host(starts, lens, Hkv)):
             got = ops.varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), ks, kl, q_len, max(lens), meta_host=meta).cpu().float()
-            check_attn(f"varlen_attn_ragged_flash2/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, rel)
+            check_attn(f"varlen_attn_ragged_flash2/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, ulp_of=dtype)
     finally:
         lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
 
@@ -660,10 +726,10 @@ def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
     want = orc.varlen_attn(q, k, v, starts, lens, q_len).float()
     ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
     kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
-    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
     for meta in (None, ops._meta_host(starts, lens, Hkv)):
         got = ops.varlen_attn(q.to(DEV), k.to(DEV), v.to(DEV), ks, kl, q_len, max(lens), meta_host=meta).cpu().float()
-        check_attn(f"varlen_attn_many_query_rows_vs_oracle/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, rel)
+        check_attn(f"varlen_attn_many_query_rows_vs_oracle/{q_len}/{dtype}/meta{meta is not None}", got, want, tol, ulp_of=dtype)
     # the decode kernel (16-row tiles, split keys) must agree with the multi-row kernel on the same call
     if q_len == 64:
         lib = ops._lib.load()
@@ -679,7 +745,10 @@ def test_varlen_attn_many_query_rows_vs_oracle(q_len, dtype):
                 outs.append(ops.varlen_attn(q2, k2, v2, ks2, kl2, 64, 2900).float())
             finally:
                 lib.kvz_debug_set_tunable(b"flash_min_rows", prev)
-        assert (outs[0] - outs[1]).abs().max() <= tol + rel * outs[1].abs().max(), float((outs[0] - outs[1]).abs().max())
+        # (two kernels, each within one output step of the exact value)
+        from conftest import grid_step
+        assert ((outs[0] - outs[1]).abs().cpu() <= 2 * torch.maximum(torch.full_like(outs[1], tol), grid_step(outs[1], dtype)).cpu()).all(), \
+            float((outs[0] - outs[1]).abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -704,8 +773,8 @@ def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
     j = torch.arange(klen, device=DEV).view(1, 1, klen)
     s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
     want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
-    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)  # + one output ulp, as above
-    check_attn(f"flash_fwd_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, rel)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
+    check_attn(f"flash_fwd_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, ulp_of=dtype)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     # the attention hook of the model forward goes through the same kernel
     from kvzip_amd.attn import dense_causal_attention
@@ -714,7 +783,8 @@ def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(28, 4, 300, 300), (28, 4, 130, 1500), (8, 2, 257, 1000), (6, 2, 70, 77), (16, 16, 129, 700), (7, 1, 1100, 2300)])
+@pytest.mark.parametrize("shape", [(28, 4, 300, 300), (28, 4, 130, 1500), (8, 2, 257, 1000), (6, 2, 70, 77), (16, 16, 129, 700), (7, 1, 1100, 2300),
+                                   (24, 8, 300, 900), (6, 3, 260, 500), (4, 4, 1300, 1300)])
 def test_flash2_dense_vs_fp32_reference(shape, dtype):
     """The 32-row forward (kvz_flash2.hip: 256-row blocks, 32x32x16 MFMA, LDS-DMA ring) forced onto shapes of every kind - several
     row tiles, a partial last row tile, fewer keys than a tile, a ragged last key tile, G = 1 and Hkv = 1, rows that see a single key -
@@ -740,17 +810,28 @@ def test_flash2_dense_vs_fp32_reference(shape, dtype):
     finally:
         lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
     assert torch.equal(out, again)
+    # round 4: the XCD-aware block order (a head's row tiles on 8 / Hkv XCDs; Hkv = 1, 2, 4, 8: XCDs per head, 16: heads per XCD,
+    # 3: head-major fallback; partial groups when 8 / Hkv does not divide the row tiles) only permutes blocks: same bits as head-major
+    prev_x = lib.kvz_debug_set_tunable(b"flash2_xcd", 0)
+    prev_b = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    try:
+        plain, lse_plain = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_xcd", prev_x)
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev_b)
+    assert prev_x == 1 and torch.equal(out, plain) and torch.equal(lse, lse_plain)
     s = torch.einsum("hid,hjd->hij", qq[0].float(), key[0].float().repeat_interleave(G, 0)) / math.sqrt(D)
     i = torch.arange(q_len, device=DEV).view(1, q_len, 1)
     j = torch.arange(klen, device=DEV).view(1, 1, klen)
     s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
     want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
-    tol, rel = (1e-3, 2.0 ** -10) if dtype == torch.float16 else (8e-3, 2.0 ** -7)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
     err = (out[0].float() - want).abs()
     print(f"\nflash2 {shape} {dtype}: max |err| {float(err.max()):.2e} (16-row kernel: {float((old[0].float() - want).abs().max()):.2e})")
-    check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, rel)
+    check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, ulp_of=dtype)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
-    assert ((out.float() - old.float()).abs() <= 2 * (tol + rel * want.abs().unsqueeze(0))).all()
+    from conftest import grid_step
+    assert ((out.float() - old.float()).abs().cpu() <= 2 * torch.maximum(torch.full_like(want, tol), grid_step(want, dtype)).unsqueeze(0).cpu()).all()
 
 
 def test_flash_attn_varlen_func_call_compatibility():

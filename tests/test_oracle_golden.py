@@ -241,5 +241,22 @@ def test_oracle_pinned_on_e2e_d128_fixture_sample():
     assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g["f16/valid"])
 
 
+def test_oracle_threshold_on_e2e_d128_512k_fixture():
+    """G10 (8 layers x 8 chunks = 512 000 reference-generated scores per dtype): the oracle's global threshold on the reference's own
+    scores reproduces the reference's threshold, mask and per-(layer, head) kept counts bit for bit (the scores themselves are
+    compared on the GPU box by tests/test_gpu_e2e_parity.py; regenerating the 1.2 GB of seeded inputs here would double the CPU suite)."""
+    import e2e_inputs as E
+    g = load_golden("g10_e2e_d128_512k.npz")
+    geom = E.GEOM_512K
+    assert [geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")] == g["geom"].tolist()
+    for tag, bf in (("f16", False), ("bf16", True)):
+        want = from_bits(g[f"{tag}/score"], bf)
+        assert tuple(want.shape) == (geom["L"], 1, geom["Hkv"], geom["N"])
+        valid, thres = orc.threshold([want[i] for i in range(geom["L"])], 0.3)
+        assert thres == float(g[f"{tag}/thres"][0])
+        assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g[f"{tag}/valid"])
+        assert np.array_equal(valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32), g[f"{tag}/kept"])
+
+
 def to_bits_t(t):
     return t.contiguous().view(torch.int16)
