@@ -65,10 +65,6 @@ def parse(argv=None):
                          "bracketed by hipEvents (kernel durations for the roofline; the GPU is idle at a step's start, nothing is "
                          "drained); all other calls overlap on the side streams")
     ap.add_argument("--unfused-update", action="store_true", help="update and _get_score as two library calls")
-    ap.add_argument("--append", default="kernel", choices=["kernel", "stream"],
-                    help="where the repeat chunk's K,V reach the dense cache in a fused update + _get_score call: 'kernel' = the scoring "
-                         "kernels copy them (no append launch; this driver never reads them back from the cache), 'stream' = a "
-                         "kvz_dense_append launch on the caller's stream (what ModelKVzip.scoring does: its forward reads the rows)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group even with one GPU and push the result gather and the max-over-ranks "
                          "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
@@ -315,9 +311,7 @@ def main(argv=None):
             prev_kv[0].close()   # (the previous step's cache: its events go back now, not when the collector gets to it)
         kv = prev_kv[0] = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
         kv.n_score_streams = max(1, args.score_streams)
-        # update + _get_score = ONE library call (what kvzip_amd.attn / ModelKVzip.scoring do); this driver owns the repeat pass's
-        # K,V and never reads them back from the cache, so by default the scoring kernels do the append themselves ("kernel")
-        kv.fuse_update_score = False if args.unfused_update else ("kernel" if args.append == "kernel" else True)
+        kv.fuse_update_score = not args.unfused_update  # what kvzip_amd.attn / ModelKVzip.scoring do: update + _get_score = one call
         kv.adopt_dense(store_k, store_v, sink + N)
         if head_level:
             # what ModelKVzip.scoring(load_score=True) leaves behind: a stride-0 view of the [L,Hkv] head scores
@@ -567,7 +561,6 @@ def main(argv=None):
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
             "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,
             "update_score_fused": not args.unfused_update,
-            "append": "two calls" if args.unfused_update else args.append,
         },
         "roofline": roofline,
         "roofline_stages": stages,

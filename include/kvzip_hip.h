@@ -127,24 +127,19 @@ int kvz_score_finalize_log(const uint32_t* log, int64_t n, void* out, int dtype,
 int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void* out, int dtype, void* select_ws, size_t select_ws_bytes,
                                 kvz_stream_t stream);
 
-/* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78)
- * followed by kvz_score_chunk_async_log on the side stream with k = k_cache, klen = fill + t.
- *   append_in_kernel = 0: kvz_dense_append on the CALLER's stream, where the forward's own attention reads the rows next.  Before the
- *     append the caller's stream is ordered behind the previous scoring call of the same slot (it read the rows that are about to be
- *     overwritten).
- *   append_in_kernel = 1 (taken when t == q_len and the rows of k_state are contiguous, ks_row_stride == D; otherwise as 0): NO append
- *     launch - the row-statistics pass stages the repeat chunk's K rows straight from k_state and its blocks copy them, and the V rows,
- *     into rows fill .. fill + t of the caches after their last tile.  The rows are then written on the SIDE stream: for callers whose
- *     stream does not read them back from the cache (a scoring driver that owns the repeat pass's Q/K/V, bench.py); a later reader
- *     orders itself behind the slot with kvz_async_wait.  Bit-identical scores and cache contents.
- * Arguments as in the two calls it replaces. */
+/* One host call for the scoring pass of a layer:  update() of the repeat chunk's K,V into the DENSE cache (attention/kvcache.py:75-78,
+ * kvz_dense_append on the CALLER's stream, where the forward's own attention reads the rows next) followed by kvz_score_chunk_async_log
+ * on the side stream with k = k_cache, klen = fill + t.  Before the append the caller's stream is ordered behind the previous scoring
+ * call of the same slot (it read the rows that are about to be overwritten).  Arguments as in the two calls it replaces.
+ * (Round 4 measured the alternative - no append launch, the scoring kernels copy the rows themselves: slower, see
+ * profiles/r4_ab_in_kernel_append.txt; the append launch co-resides with the scoring kernels of the side streams and costs nothing.) */
 int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side,
                                void* k_cache, void* v_cache, int64_t cache_head_stride, int fill,
                                const void* k_state, const void* v_state,
                                int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride, int64_t vs_row_stride, int t,
                                const void* q, int64_t q_head_stride, int sink, int start, int end, int q_len,
                                int Hkv, int G, int D, int dtype,
-                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, int append_in_kernel);
+                               uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

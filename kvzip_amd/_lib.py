@@ -35,7 +35,7 @@ SIGNATURES = {
     "kvz_score_chunk_async_log": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp,
                                        _sz]),
     "kvz_update_score_async_log": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i64, _i, _i, _i,
-                                        _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _i]),
+                                        _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz]),
     "kvz_score_from_stats_log": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
     "kvz_score_from_stats_async_log": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64]),
     "kvz_flash_fwd_window": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i64, _i64, _i64, _i, _i, _i, _vp,

@@ -258,44 +258,13 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
 }
 
 
-// one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache, then score
+// one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache on the caller's stream, then score
 extern "C" int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, void* k_cache, void* v_cache,
                                           int64_t cache_head_stride, int fill, const void* k_state, const void* v_state,
                                           int64_t ks_head_stride, int64_t ks_row_stride, int64_t vs_head_stride,
                                           int64_t vs_row_stride, int t, const void* q, int64_t q_head_stride, int sink, int start,
                                           int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out,
-                                          int64_t log_head_stride, void* ws, size_t ws_bytes, int append_in_kernel) {
-    if (append_in_kernel && t == q_len && ks_row_stride == D) {
-        // the row-statistics pass stages the repeat chunk's K rows straight from k_state and its blocks write them, and the V
-        // rows, into the caches after their last tile: no append launch, nothing on the caller's stream but the "inputs ready"
-        // event.  Whoever reads rows fill .. fill + t of the caches afterwards must be ordered behind this slot (kvz_async_wait).
-        kvz::AsyncCtx* c = kvz::async_get(handle);
-        KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_update_score_async_log: bad handle %d", handle);
-        KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_update_score_async_log: bad slot %d", slot);
-        KVZ_REQUIRE(k_cache && v_cache && k_state && v_state && fill >= 0 && (int64_t)(fill + t) * D <= cache_head_stride, KVZ_EINVAL,
-                    "kvz_update_score_async_log: bad append (rows %d..%d of a head of %lld elements)", fill, fill + t, (long long)cache_head_stride);
-        if (side != caller) {
-            if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
-                hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess ||
-                // (the previous call of the slot read - and wrote - the same cache rows; normally it ran on this very side stream)
-                (c->pending[slot] && hipStreamWaitEvent((hipStream_t)side, c->done[slot], 0) != hipSuccess)) {
-                kvz::set_error("kvz_update_score_async_log: could not order the side stream");
-                return KVZ_ELAUNCH;
-            }
-        }
-        const int rc = kvz::score_chunk_log_append(q, q_head_stride, k_cache, v_cache, cache_head_stride, fill + t, k_state, ks_head_stride,
-                                                   v_state, vs_head_stride, vs_row_stride, sink, start, end, q_len, Hkv, G, D, dtype,
-                                                   log_out, log_head_stride, ws, ws_bytes, (hipStream_t)side);
-        if (rc != KVZ_OK) return rc;
-        if (side != caller) {
-            if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {
-                kvz::set_error("kvz_update_score_async_log: hipEventRecord failed");
-                return KVZ_ELAUNCH;
-            }
-            c->pending[slot] = 1;
-        }
-        return KVZ_OK;
-    }
+                                          int64_t log_head_stride, void* ws, size_t ws_bytes) {
     // the previous scoring call of this slot read the rows that the append overwrites
     int rc = kvz_async_wait(handle, slot, caller);
     if (rc != KVZ_OK) return rc;

@@ -55,12 +55,6 @@ int tunable(Tunable t);
 // exact-reciprocal constant of the scoring rounding chain (kvz_score.hip): half(x * r) == half(x / sqrt(D)) for every 16-bit x, or 0
 float score_exact_reciprocal(int D, int dtype);
 
-// kvz_score_chunk_log whose row-statistics pass appends the repeat chunk's K,V to the dense caches itself (kvz_score.hip)
-int score_chunk_log_append(const void* q, int64_t q_head_stride, void* k_cache, void* v_cache, int64_t cache_head_stride, int klen,
-                           const void* k_state, int64_t ks_head_stride, const void* v_state, int64_t vs_head_stride,
-                           int64_t vs_row_stride, int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
-                           uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, hipStream_t stream);
-
 // the 32-row dense forward (kvz_flash2.hip), reached through kvz_flash_fwd
 bool flash2_takes(int Hkv, int G, int q_len, int D);
 int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k, const void* v,

@@ -63,11 +63,6 @@ __device__ static inline void lds_dma16a(const char* sbase /* wave-uniform */, u
                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(bs), "s"(la) : "memory");
 }
-// per-lane 64-bit source address, LDS destination as a byte address (sources that live in two allocations)
-__device__ static inline void lds_dma16v(const char* gsrc, uint32_t lds_byte /* wave-uniform */) {
-    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_byte);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");
-}
 __device__ static inline void lds_dma16s(const char* sbase /* wave-uniform */, uint32_t voff, const char* lds_dst /* wave-uniform */) {
     lds_dma16a(sbase, voff, lds_addr(lds_dst));
 }

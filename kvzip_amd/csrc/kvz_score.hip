@@ -78,15 +78,6 @@ struct ScoreArgs {
     FastDiv dq, dh;      // q_len, Hkv
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
-    // in-kernel append (round 4; reference EvictCache.update, attention/kvcache.py:41-80, in front of _get_score): the repeat
-    // chunk's K rows are NOT in the cache yet - pass A stages them from `krep` ([Hkv, q_len, D], rows contiguous) and the blocks of
-    // pass B copy them, and the chunk's V rows, into rows klen - q_len .. klen - 1 of the K / V caches after their tile loop.
-    // NULL: the rows are in the cache already (a separate append launch, or a plain scoring call).
-    const void* krep;
-    int64_t krep_head_stride;      // elements
-    void* app_v;                   // V cache [Hkv, cache head stride = k_head_stride, D]
-    const void* vrep;              // [Hkv, q_len, D] with element strides (head, row)
-    int64_t vrep_head_stride, vrep_row_stride;
 };
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
@@ -497,8 +488,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     const uint32_t lds0 = lds_addr(lds);
     const char* const kbase = reinterpret_cast<const char*>(a.k);
     const int64_t khs = a.k_head_stride * 2;
-    const char* const krep0 = reinterpret_cast<const char*>(a.krep);  // null: the repeat chunk's rows are in the cache
-    const int64_t kreps = a.krep_head_stride * 2;
     auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
         const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
         const char* kh = kbase + (int64_t)h * khs;
@@ -509,13 +498,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         else if (t >= tr_lo && t < tr_hi) off = off_rep;
         else if (t >= ts_hi) linear = false;
         if (linear) {
-            const bool rep_tile = krep0 != nullptr && t >= tr_lo && t < tr_hi;  // (wave-uniform)
-            const char* base = rep_tile ? krep0 + (int64_t)h * kreps + (int64_t)(kv0 - diag0) * C::ROW_BYTES
-                                        : kh + (int64_t)(kv0 + off) * C::ROW_BYTES;
-            stage_tile_linear_a<D, NWAVES>(dst, base, lane_off, wave);
+            stage_tile_linear_a<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
         } else {  // (inlined: a call would open with s_waitcnt vmcnt(0) and drain the tiles in flight)
             constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
-            const char* const krh = krep0 ? krep0 + (int64_t)h * kreps : nullptr;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int ci = i * NWAVES + wave;  // wave-uniform 1-KiB piece of the tile
@@ -523,16 +508,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                 const int pch = lane % C::CPR;
                 const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
                 const int kv = min(kv0 + row, KT - 1);
-                if (krh) {
-                    // the repeat chunk's rows come from another allocation: a 64-bit address per lane (tiles that straddle a
-                    // segment boundary or the end only - at most three per item)
-                    const int crow = kv + (kv < a.sink ? 0 : off_ctx);
-                    const char* src = (kv < diag0 ? kh + (int64_t)crow * C::ROW_BYTES : krh + (int64_t)(kv - diag0) * C::ROW_BYTES) + chunk * 16;
-                    lds_dma16v(src, dst + (uint32_t)(ci * 1024));
-                } else {
-                    const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
-                    lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
-                }
+                const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
+                lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
             }
         }
     };
@@ -856,6 +833,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
             frag_load<D>(fr[1], fa0, b1 * C::TILE_BYTES + 32 * C::ROW_BYTES);
         }
     };
+    (void)diag0;
 
     chain0(acc[0], fr[0]);
     while (true) {
@@ -942,33 +920,6 @@ __device__ static inline float2 merge_row_stats(const float2* __restrict__ stats
     const float delta = __builtin_fmaf(M, L2E, -ML2);
     return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
-// ---- in-kernel append (round 4): this block's share of the repeat chunk's K and V rows -> rows klen - q_len .. of the caches.
-// Called by every block of pass B after its tile loop (no LDS-DMA in flight any more, the kernel has register room, and pass A -
-// which read the K rows from `krep` - is over): 2 * Hkv * q_len rows over ~256 blocks = 16 KiB per block.
-template <int D>
-__device__ static inline void score_append_rows(const ScoreArgs& a, int nthreads) {
-    if (!a.krep) return;
-    constexpr int ROW_BYTES = D * 2, CPR = ROW_BYTES / 16;
-    const int64_t per_head = (int64_t)a.q_len * CPR;          // 16-byte chunks per head
-    const int64_t half_total = per_head * a.n_kv_heads;       // K, then as many for V
-    const int64_t total = 2 * half_total;
-    const int64_t share = (total + gridDim.x - 1) / gridDim.x;
-    const int64_t c_end = min(total, (int64_t)(blockIdx.x + 1) * share);
-    const int fill = a.klen - a.q_len;
-    const int64_t khs = a.k_head_stride * 2, kreps = a.krep_head_stride * 2, vhs = a.vrep_head_stride * 2, vrs = a.vrep_row_stride * 2;
-    for (int64_t c = (int64_t)blockIdx.x * share + threadIdx.x; c < c_end; c += nthreads) {
-        const bool is_v = c >= half_total;
-        const int64_t cc = is_v ? c - half_total : c;
-        const int hh = (int)(cc / per_head);
-        const int rr = (int)((cc - hh * per_head) / CPR), ch = (int)(cc % CPR);
-        const char* src = is_v ? reinterpret_cast<const char*>(a.vrep) + hh * vhs + rr * vrs + ch * 16
-                               : reinterpret_cast<const char*>(a.krep) + hh * kreps + (int64_t)rr * ROW_BYTES + ch * 16;
-        char* dst = (is_v ? reinterpret_cast<char*>(a.app_v) : reinterpret_cast<char*>(const_cast<void*>(a.k))) + hh * khs +
-                    (int64_t)(fill + rr) * ROW_BYTES + ch * 16;
-        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-    }
-}
-
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a) {
     constexpr int NWAVES = PB_WAVES;
@@ -1251,7 +1202,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             }
         }
     }
-    score_append_rows<D>(a, NWAVES * 64);
 }
 
 template <typename T>
@@ -1508,18 +1458,10 @@ extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, in
     return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len);
 }
 
-// the repeat chunk's K,V that pass A appends to the caches itself (kvz_update_score_async_log with append_in_kernel)
-struct ScoreAppend {
-    const void* k_state;
-    const void* v_state;
-    void* v_cache;
-    int64_t ks_head_stride, vs_head_stride, vs_row_stride;  // elements
-};
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0,
-                            const ScoreAppend* app = nullptr);
+                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0);
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                                int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
@@ -1535,17 +1477,6 @@ extern "C" int kvz_score_chunk_log(const void* q, int64_t q_head_stride, const v
     KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_chunk_log: bad log buffer");
     return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
                             log_head_stride, ws, ws_bytes, stream_);
-}
-
-// scoring call whose pass A also appends the repeat chunk's K,V (k_state rows contiguous) to rows klen - q_len .. of the caches
-int kvz::score_chunk_log_append(const void* q, int64_t q_head_stride, void* k_cache, void* v_cache, int64_t cache_head_stride, int klen,
-                                const void* k_state, int64_t ks_head_stride, const void* v_state, int64_t vs_head_stride,
-                                int64_t vs_row_stride, int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype,
-                                uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes, hipStream_t stream) {
-    KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_update_score_async_log: bad log buffer");
-    const ScoreAppend app{k_state, v_state, v_cache, ks_head_stride, vs_head_stride, vs_row_stride};
-    return score_chunk_impl(q, q_head_stride, k_cache, cache_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0,
-                            log_out, log_head_stride, ws, ws_bytes, (kvz_stream_t)stream, nullptr, 0, &app);
 }
 
 extern "C" int kvz_score_from_stats_log(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -1602,7 +1533,7 @@ extern "C" int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void*
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride, const ScoreAppend* app) {
+                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && (out || log_out) && (ws || merged_stats), KVZ_EINVAL, "kvz_score_chunk: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
@@ -1636,15 +1567,6 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     }
     a.out = out; a.out_head_stride = out_head_stride;
     a.log_out = log_out; a.log_head_stride = log_head_stride;
-    if (app) {
-        KVZ_REQUIRE(!merged_stats && app->k_state && app->v_state && app->v_cache, KVZ_EINVAL, "kvz_score_chunk: bad in-kernel append");
-        KVZ_REQUIRE(aligned16(app->k_state) && aligned16(app->v_state) && aligned16(app->v_cache) &&
-                        (app->ks_head_stride * 2) % 16 == 0 && (app->vs_head_stride * 2) % 16 == 0 && (app->vs_row_stride * 2) % 16 == 0,
-                    KVZ_EINVAL, "kvz_score_chunk: the appended K,V must be 16-byte aligned with strides that are multiples of 8 elements");
-        a.krep = app->k_state; a.krep_head_stride = app->ks_head_stride;
-        a.app_v = app->v_cache; a.vrep = app->v_state;
-        a.vrep_head_stride = app->vs_head_stride; a.vrep_row_stride = app->vs_row_stride;
-    }
     a.dq = make_fastdiv(q_len);
     a.dh = make_fastdiv(Hkv);
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}

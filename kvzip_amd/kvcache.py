@@ -66,12 +66,7 @@ class _CacheBase(KVScore):
         self._pend_app = None                    # append left by update() for the fused update + score call of _get_score
         # scoring pass: update() leaves its append to the _get_score() call that follows it (attention/attn.py:44-54) and the two
         # become ONE library call.  Between the two calls the returned K,V views do not hold the new rows yet, so this is opt-in:
-        # kvzip_amd.attn (the forward pass this package owns) and ModelKVzip.scoring switch it on (True: the append is a launch on
-        # the caller's stream, where the forward's own attention reads the rows next).  "kernel": no append launch at all - the
-        # row-statistics kernel stages the chunk's K rows from key_states and writes K and V into the cache itself, on the scoring
-        # side stream; for drivers whose stream does not read the chunk's rows back from the cache before slice() (they own the repeat
-        # pass's Q/K/V: bench.py, a serving engine that scores from its own KV pages); every reader inside this class orders itself
-        # behind the scoring call (_wait_score)
+        # kvzip_amd.attn (the forward pass this package owns) and ModelKVzip.scoring switch it on
         self.fuse_update_score = False
 
     # -- dense (pre-prune) storage --------------------------------------------------------------

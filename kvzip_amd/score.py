@@ -309,18 +309,11 @@ class KVScore:
             _, ks, vs, fill = pend
             sk, sv = self._store_k[layer_idx], self._store_v[layer_idx]
             out_ptr = log.data_ptr() + (layer_idx * Hkv * n_tot + f) * 4
-            in_kernel = 1 if self.fuse_update_score == "kernel" else 0
-            if in_kernel and nstreams > 1:
-                ks.record_stream(st)   # the side stream reads the chunk's K,V itself (pass A stages / copies them)
-                vs.record_stream(st)
             rc = lib.kvz_update_score_async_log(self._async, layer_idx, cur, side, sk.data_ptr(), sv.data_ptr(), sk.stride(1), fill,
                                                 ks.data_ptr(), vs.data_ptr(), ks.stride(1), ks.stride(2), vs.stride(1), vs.stride(2),
                                                 ks.shape[-2], query_states.data_ptr(), query_states.stride(1), self.sink,
                                                 self.start_idx, self.end_idx, q_len, Hkv, H // Hkv, D,
-                                                ops._dtype_code(query_states.dtype), out_ptr, n_tot, ws.data_ptr(), ws.numel(),
-                                                in_kernel)
-            if in_kernel:
-                self._pending = True   # (also on one stream: readers of the cache rows go through _wait_score)
+                                                ops._dtype_code(query_states.dtype), out_ptr, n_tot, ws.data_ptr(), ws.numel())
             self._log_dirty = True
         elif log is not None and log.shape[-1] == n_tot:
             # deferred path: pass B merges its row slices by atomics into the log buffer, the finalize launch happens once, when

@@ -431,66 +431,3 @@ def test_score_forward_fused_statistics(dtype):
     d = ulp_diff(s_fused, s_two)
     print(f"fused vs two-pass {dtype}: {float((d == 0).float().mean()):.5f} identical, worst {int(d.max())}")
     assert (d == 0).float().mean() >= 0.995 and d.max() <= 2
-
-
-@pytest.mark.parametrize("geom", [
-    # (L, H, Hkv, D, sink, N, chunk, extra): tiles that straddle sink / ctx / repeat boundaries in every combination
-    (4, 8, 2, 128, 16, 1536, 256, 9),      # repeat chunk shorter than two tiles, ctx not tile aligned
-    (3, 14, 2, 128, 32, 2000, 1000, 26),   # the bench's alignment: sink 32, chunks of 1000 + 26 rows
-    (3, 4, 2, 64, 8, 1024, 512, 13),       # head dim 64 (8 rows per LDS-DMA piece)
-    (2, 7, 1, 128, 0, 640, 128, 3),        # no sink, one KV head, ctx chunk exactly one tile
-])
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_in_kernel_append_equals_stream_append(geom, dtype):
-    """Round 4: with ``fuse_update_score = "kernel"`` the scoring kernels append the repeat chunk themselves (pass A stages the
-    chunk's K rows from ``key_states``, the blocks of pass B copy K and V into the cache): NO append launch.  Scores, thresholds,
-    masks and the cache rows of the repeat chunk must be bit-identical to the stream append (``True``) and to the two-call form,
-    on one and on three streams, with V as a strided view (what a projection hands over)."""
-    from kvzip_amd.kvcache import EvictCache
-    L, H, Hkv, D, sink, N, chunk, extra = geom
-    cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
-    g = torch.Generator(device=DEV).manual_seed(4321)
-    K = [torch.randn(1, Hkv, sink + N, D, generator=g, device=DEV).to(dtype) for _ in range(L)]
-    V = [torch.randn(1, Hkv, sink + N, D, generator=g, device=DEV).to(dtype) for _ in range(L)]
-    chunks = [(sink + c, min(sink + c + chunk, sink + N)) for c in range(0, N, chunk)]
-    q_in = [[torch.randn(1, H, (en - st) + extra, D, generator=g, device=DEV).to(dtype) for _ in range(L)] for st, en in chunks]
-    k_in = [[torch.randn(1, Hkv, (en - st) + extra, D, generator=g, device=DEV).to(dtype) for _ in range(L)] for st, en in chunks]
-    # V straight out of a projection: [1, t, Hkv, D] viewed as [1, Hkv, t, D] (row stride Hkv*D)
-    v_in = [[torch.randn(1, (en - st) + extra, Hkv, D, generator=g, device=DEV).to(dtype).transpose(1, 2) for _ in range(L)]
-            for st, en in chunks]
-
-    def run(mode, nstreams):
-        kv = EvictCache(cfg, (sink, sink + N), device=DEV, dtype=dtype, verbose=False)
-        kv.n_score_streams = nstreams
-        kv.fuse_update_score = mode
-        for l in range(L):
-            kv.update(K[l], V[l], l)
-        kv.init_score()
-        rows = []
-        for c, (st, en) in enumerate(chunks):
-            kv.start_idx, kv.end_idx = st, en
-            seen = kv._seen_tokens
-            for l in range(L):
-                k_all, _ = kv.update(k_in[c][l], v_in[c][l], l)
-                kv._get_score(q_in[c][l], k_all, l)
-            if c in (0, len(chunks) - 1):   # the appended rows as the cache holds them (readers order themselves behind the scoring)
-                kv._wait_score(finalize=False)
-                t = k_in[c][0].shape[2]
-                rows.append([(kv._store_k[l][:, :, seen:seen + t].clone(), kv._store_v[l][:, :, seen:seen + t].clone()) for l in range(L)])
-            kv.slice(seen)
-        kv.start_idx, kv.get_score = sink, False
-        score = torch.stack([s.clone() for s in kv.score])
-        thres, r_real = kv.prune(0.4)
-        return score, thres, kv.valid.clone(), rows
-
-    s0, t0, v0, r0 = run(False, 1)          # update and _get_score as two calls
-    for c, ci in enumerate((0, len(chunks) - 1)):   # (sanity of the comparison itself: the rows are the inputs)
-        for l in range(L):
-            assert torch.equal(r0[c][l][0], k_in[ci][l]) and torch.equal(r0[c][l][1], v_in[ci][l])
-    for mode, n in ((True, 1), ("kernel", 1), ("kernel", 3), ("kernel", 3), (True, 3)):
-        s1, t1, v1, r1 = run(mode, n)
-        assert torch.equal(s0.view(torch.int16), s1.view(torch.int16)), (mode, n)
-        assert t0 == t1 and torch.equal(v0, v1), (mode, n)
-        for a, b in zip(r0, r1):
-            for (ka, va), (kb, vb) in zip(a, b):
-                assert torch.equal(ka, kb) and torch.equal(va, vb), (mode, n)

@@ -774,7 +774,7 @@ def test_flash_fwd_dense_vs_fp32_reference(shape, dtype):
     s = s.masked_fill(j > i + (klen - q_len), float("-inf"))
     want = torch.einsum("hij,hjd->ihd", torch.softmax(s, -1), val[0].float().repeat_interleave(G, 0))
     tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
-    check_attn(f"flash_fwd_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, ulp_of=dtype)
+    check_attn(f"flash_fwd_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want.to(dtype), tol, ulp_of=dtype)   # (the oracle's contract: fp32 result rounded once)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     # the attention hook of the model forward goes through the same kernel
     from kvzip_amd.attn import dense_causal_attention
@@ -828,7 +828,7 @@ def test_flash2_dense_vs_fp32_reference(shape, dtype):
     tol = 1e-3 if dtype == torch.float16 else 8e-3   # (one output step where the grid is coarser than that: conftest.check_attn)
     err = (out[0].float() - want).abs()
     print(f"\nflash2 {shape} {dtype}: max |err| {float(err.max()):.2e} (16-row kernel: {float((old[0].float() - want).abs().max()):.2e})")
-    check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want, tol, ulp_of=dtype)
+    check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want.to(dtype), tol, ulp_of=dtype)   # (the oracle's contract: fp32 result rounded once)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     from conftest import grid_step
     assert ((out.float() - old.float()).abs().cpu() <= 2 * torch.maximum(torch.full_like(want, tol), grid_step(want, dtype)).unsqueeze(0).cpu()).all()

@@ -9,8 +9,7 @@ part=${1:-ab}
 if [ $part = ab ]; then
   for i in 1 2; do
     (cd tools/ab/r3_tree && python bench.py --steps 10 --warmup 2 --no-cpu-baseline --decode-tokens 8 > $O/ab_r3_$i.json 2> $O/ab_r3_$i.err)
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --decode-tokens 8 > $O/ab_r4_kernel_$i.json 2> $O/ab_r4_kernel_$i.err
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --decode-tokens 8 --append stream > $O/ab_r4_stream_$i.json 2> $O/ab_r4_stream_$i.err
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --decode-tokens 8 > $O/ab_r4_$i.json 2> $O/ab_r4_$i.err
   done
   python - <<PY
 import json, glob, os
