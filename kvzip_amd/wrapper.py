@@ -105,10 +105,16 @@ class ModelKVzip:
         self.fuse_forward_score = False
         self.head_score_dir = head_score_dir
         self.cache_kwargs = dict(cache_kwargs or {})
-        self.gen_kwargs = {"do_sample": False, "max_new_tokens": max_new_tokens}
+        # the reference's generation settings (model/wrapper.py:81-94): greedy by default, the sampling knobs of HF generate under
+        # the same names; Qwen3 stops at <|im_end|> = 151645 like there
+        self.gen_kwargs = {"do_sample": False, "temperature": 1.0, "top_p": 1, "top_k": None, "max_new_tokens": max_new_tokens}
+        if eos_token_id is None and getattr(self.config, "model_type", "") == "qwen3":
+            eos_token_id = 151645
         if eos_token_id is None:
             eos_token_id = getattr(model.generation_config, "eos_token_id", None) if hasattr(model, "generation_config") else None
-        self.eos_token_ids = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id or [])
+        if eos_token_id is not None:
+            self.gen_kwargs["eos_token_id"] = eos_token_id
+        self.sample_generator: Optional[torch.Generator] = None   # seed source of do_sample=True (None: torch's global generator)
         self.sys_prompt_ids = torch.zeros((1, 0), dtype=torch.long, device=self.device)
         self.postfix_ids = torch.zeros((1, 0), dtype=torch.long, device=self.device)
         if tokenizer is not None:
@@ -236,13 +242,48 @@ class ModelKVzip:
             kv.score = load_head_score(self.name, kv.ctx_len, self.head_score_dir, self.device)
         kv.get_score = False
 
+    @property
+    def eos_token_ids(self) -> List[int]:
+        e = self.gen_kwargs.get("eos_token_id")
+        return [e] if isinstance(e, int) else list(e or [])
+
+    @staticmethod
+    def next_token(logits: torch.Tensor, gen_kwargs: dict, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Next token ``[b, 1]`` from last-position logits ``[b, V]`` under the reference's ``gen_kwargs`` (model/wrapper.py:81-87,
+        passed to HF ``generate`` there): ``do_sample=False`` -> argmax; otherwise temperature, then top-k, then top-p (nucleus: the
+        smallest set of most probable tokens whose mass reaches ``top_p``, at least one token), then one multinomial draw - the
+        order and the semantics of transformers' logits warpers."""
+        if not gen_kwargs.get("do_sample", False):
+            return logits.argmax(-1, keepdim=True)
+        x = logits.float()
+        t = gen_kwargs.get("temperature", 1.0)
+        if t is not None and t != 1.0:
+            x = x / float(t)
+        k = gen_kwargs.get("top_k")
+        if k:
+            kth = torch.topk(x, min(int(k), x.shape[-1]), dim=-1).values[..., -1:]
+            x = x.masked_fill(x < kth, float("-inf"))
+        p = gen_kwargs.get("top_p", 1)
+        if p is not None and p < 1:
+            sx, si = torch.sort(x, dim=-1, descending=False)
+            cum = torch.softmax(sx, dim=-1).cumsum(-1)
+            drop = cum <= (1 - float(p))          # the low-probability tail whose mass stays below 1 - top_p
+            drop[..., -1:] = False                # (at least the most probable token survives)
+            x = x.masked_fill(torch.zeros_like(drop).scatter(-1, si, drop), float("-inf"))
+        return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=generator)
+
     # ---- generation (reference model/wrapper.py:251-284) ---------------------------------------------------------
     @_on_model_device
     @torch.inference_mode()
     def generate(self, query: Union[str, torch.Tensor], kv=None, update_cache: bool = False,
                  return_ids: bool = False):
-        """Greedy response to ``query``.  The KV of the query and of the answer is evicted afterwards
-        (``kv.slice``) unless ``update_cache=True`` (multi-turn)."""
+        """Response to ``query`` under ``self.gen_kwargs`` (the reference's knobs, model/wrapper.py:81-94: greedy by default;
+        ``do_sample / temperature / top_k / top_p / max_new_tokens / eos_token_id`` as HF ``generate`` takes them there).  The
+        reference hands the loop to ``model.generate(input_ids, past_key_values=kv, **gen_kwargs)`` (model/wrapper.py:276); the
+        token loop lives here because the cache object is not a ``transformers.Cache`` subclass in transformers 5.x - same tokens
+        for the same knobs, and like there the prompt is only what is new (HF slices ``input_ids[:, -new:]`` off the full
+        sequence).  The KV of the query and of the answer is evicted afterwards (``kv.slice``) unless ``update_cache=True``
+        (multi-turn)."""
         kv = self._init_kv(kv=kv)
         seen_token_prev = kv._seen_tokens
         input_ids = self.encode(query) if isinstance(query, str) else query.to(self.device)
@@ -250,7 +291,7 @@ class ModelKVzip:
         cur = input_ids
         for _ in range(self.gen_kwargs["max_new_tokens"]):
             logits = self.model(cur, past_key_values=kv, use_cache=True).logits[:, -1]
-            nxt = logits.argmax(-1, keepdim=True)
+            nxt = self.next_token(logits, self.gen_kwargs, self.sample_generator)
             out_ids.append(nxt)
             if self.eos_token_ids and int(nxt) in self.eos_token_ids:
                 break

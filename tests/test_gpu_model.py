@@ -166,6 +166,58 @@ def test_eval_ratios_retain_cache():
         m2.eval_ratios(ke, [0.5], lambda kv: None)
 
 
+def compare_probs(p1: torch.Tensor, p2: torch.Tensor, label: torch.Tensor) -> dict:
+    """Full-cache vs evicted-cache next-token probabilities on the answer positions: the statistics of the reference's
+    ``Evaluator._compare`` (utils/tester.py:61-109, restated: test infrastructure).  ``p1`` / ``p2``: ``[T, V]`` probabilities over
+    ``q ++ a``; ``label``: the answer ids.  -> answer-probability difference, top1-top2 margin difference, distribution difference
+    (each as (min, mean |.|, max)) and the positions whose top-1 prediction flips."""
+    p1, p2 = p1[-len(label) - 1:-1].float(), p2[-len(label) - 1:-1].float()      # tester.py:63-64
+    pred1, pred2 = p1.argmax(1), p2.argmax(1)
+    pans1 = torch.gather(p1, 1, label.unsqueeze(1)).squeeze(1)
+    pans2 = torch.gather(p2, 1, label.unsqueeze(1)).squeeze(1)
+
+    def stat(t):
+        return (t.min().item(), t.abs().mean().item(), t.max().item())
+    prev, post = torch.topk(p1, 2, dim=1).values, torch.topk(p2, 2, dim=1).values
+    margin1, margin2 = prev[:, 0] - prev[:, 1], post[:, 0] - post[:, 1]
+    flip = torch.nonzero(pred1 != pred2, as_tuple=True)[0]
+    post_prev = torch.gather(p2, 1, pred1.unsqueeze(1)).squeeze(1)
+    margin2[flip] = post_prev[flip] - post[flip, 0]                              # tester.py:88-89
+    return {"p_ans": stat(pans2 - pans1), "margin": stat(margin2 - margin1), "p": stat(p2 - p1), "idx_flip": flip.tolist()}
+
+
+def test_full_vs_pruned_probabilities_like_the_reference_evaluator():
+    """the reference judges an eviction by comparing the next-token probabilities of the FULL cache with those of the
+    pruned one on (query ++ answer) (utils/tester.py:46-60 ``forward`` -> ``_compare``).  Same procedure through this package:
+    ``ModelKVzip._prob`` with the dense cache, then after ``kv.prune(ratio)``.  Ratio 1.0 evicts nothing: every statistic must be
+    (numerically) zero and no prediction may flip; EvictCache and RetainCache must give the same statistics at every ratio; and
+    the distance from the full cache must not shrink when more is evicted (0.9 -> 0.5 -> 0.1, mean |p diff|)."""
+    m, ctx, rep, query = make("retain")
+    g = torch.Generator().manual_seed(9)
+    answer = torch.randint(0, 160, (1, 8), generator=g).to(DEV)
+    qa = torch.cat([m.apply_template(query), answer], dim=1)
+    kr = prefill_and_score(m, ctx, rep)
+    p_full = m._prob(qa, kr)                                   # dense cache: nothing pruned yet
+    me, _, _, _ = make("evict")
+    dist = []
+    for ratio in (1.0, 0.9, 0.5, 0.1):
+        kr.prune(ratio)
+        res_r = compare_probs(p_full, m._prob(qa, kr), answer[0])
+        ke = prefill_and_score(me, ctx, rep)
+        ke.prune(ratio)
+        res_e = compare_probs(p_full, me._prob(qa, ke), answer[0])
+        print(f"\nEVAL ratio {ratio}: p_ans {res_e['p_ans']}, margin {res_e['margin']}, p {res_e['p']}, flips {res_e['idx_flip']}")
+        # (a random-init model predicts near-uniformly over its 160 tokens: top-1 sits on near-ties, so a flip may come and go with the
+        # last bits of two attention kernels; the probability statistics themselves must agree)
+        assert len(set(res_e["idx_flip"]) ^ set(res_r["idx_flip"])) <= 2
+        for k in ("p_ans", "margin", "p"):
+            assert all(abs(a - b) <= 2e-3 for a, b in zip(res_e[k], res_r[k])), (ratio, k, res_e[k], res_r[k])
+        if ratio == 1.0:
+            assert len(res_e["idx_flip"]) <= 1 and max(abs(x) for k in ("p_ans", "p") for x in res_e[k]) <= 2e-3
+        dist.append(res_e["p"][1])
+    assert dist[0] <= dist[1] + 1e-4 and dist[1] <= dist[3] + 1e-3, dist
+
+
 class _ByteTokenizer:
     """Tokenizer stand-in (there is no network for a real one): bytes modulo the vocabulary."""
     def encode(self, text, add_special_tokens=False, return_tensors="pt"):

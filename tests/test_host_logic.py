@@ -232,3 +232,37 @@ def test_fastdiv_matches_integer_division():
                 continue
             assert lib.kvz_debug_fastdiv(d, n, C.byref(q), C.byref(r)) == 0
             assert (q.value, r.value) == (n // d, n % d), (d, n, q.value, r.value)
+
+
+def test_next_token_follows_hf_generate_knobs():
+    """ModelKVzip.generate keeps the reference's gen_kwargs (model/wrapper.py:81-94: do_sample / temperature / top_k / top_p, handed to
+    HF generate there).  The token choice is restated in ModelKVzip.next_token: greedy = argmax, and with sampling the SUPPORT and the
+    probabilities after temperature -> top-k -> top-p must be those of transformers' own logits warpers."""
+    import torch
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from kvzip_amd.wrapper import ModelKVzip as M
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(3, 200, generator=g) * 3
+    assert torch.equal(M.next_token(logits, {"do_sample": False, "temperature": 0.3, "top_k": 5}), logits.argmax(-1, keepdim=True))
+    for kw in ({"temperature": 0.7, "top_k": 12, "top_p": 0.8}, {"temperature": 1.0, "top_k": None, "top_p": 0.5},
+               {"temperature": 1.3, "top_k": 3, "top_p": 1}, {"temperature": 1.0, "top_k": None, "top_p": 1}):
+        x = logits.clone()
+        ids = torch.zeros(3, 1, dtype=torch.long)
+        if kw["temperature"] != 1.0:
+            x = TemperatureLogitsWarper(kw["temperature"])(ids, x)
+        if kw["top_k"]:
+            x = TopKLogitsWarper(kw["top_k"])(ids, x)
+        if kw["top_p"] < 1:
+            x = TopPLogitsWarper(kw["top_p"])(ids, x)
+        want = torch.softmax(x, -1)
+        # empirical check of the support: many draws never leave it, and the most probable token dominates as it should
+        draws = torch.cat([M.next_token(logits, dict(kw, do_sample=True), g) for _ in range(400)], dim=1)   # [3, 400]
+        for b in range(3):
+            support = set(torch.nonzero(want[b] > 0).view(-1).tolist())
+            assert set(draws[b].tolist()) <= support, kw
+            top = int(want[b].argmax())
+            freq = float((draws[b] == top).float().mean())
+            assert abs(freq - float(want[b, top])) < 0.12, (kw, freq, float(want[b, top]))
+    # degenerate knobs reduce to greedy
+    assert torch.equal(M.next_token(logits, {"do_sample": True, "top_k": 1}, g), logits.argmax(-1, keepdim=True))
+    assert torch.equal(M.next_token(logits, {"do_sample": True, "top_p": 1e-9}, g), logits.argmax(-1, keepdim=True))
