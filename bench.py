@@ -475,7 +475,7 @@ def main(argv=None):
     pmc = {}
     try:
         if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9 and not head_level:
-            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(path):
                     pmc = json.load(open(path))
@@ -490,7 +490,10 @@ def main(argv=None):
                                "frac": (attn_gbs / HBM_PEAK_GBS) if attn_gbs else None,
                                "avg_ms": (attn_ms / attn_n) if attn_n else None, "launches": attn_n,
                                "algorithmic_bytes": decode_bytes / L,
-                               "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes")},
+                               "traffic": pmc.get("varlen_attn_split", {}).get("traffic_bytes"),
+                               # the same stage from the un-bracketed token loop (two hipEvent records per launch pair cost ~3 us)
+                               "loop_us_per_layer": (t_dec / T / L * 1e6) if T else None,
+                               "frac_loop": (decode_bytes / L / (t_dec / T / L) / 1e9 / HBM_PEAK_GBS) if T else None},
     }
     if ragged is not None:
         stages["decode_varlen_attn_ragged"] = ragged
@@ -537,6 +540,23 @@ def main(argv=None):
                      f"the others overlap on {max(1, args.score_streams)} side streams; traffic: separate rocprofv3 --pmc passes "
                      "(profiles/*_pmc_traffic.json)"),
         }
+        # The bound that actually binds the scoring kernels is the VALU issue port (the reference's rounding chain + one exponential
+        # per logit: 5 VALU instructions per logit beside 1/128 MFMA), not the matrix pipe: VALU wave-instructions per launch (PMC
+        # SQ_INSTS_VALU, profiles/*_pmc_traffic.json) x the measured issue cost per instruction (SQ_ACTIVE_INST_VALU quad-cycles x 4 /
+        # SQ_INSTS_VALU = 4.6 clk) / 1024 SIMDs / the clock under load = the time the kernel would take if its VALU stream issued
+        # back to back; `frac` = that time / the measured duration
+        sq = pmc.get("_sq_counters", {}).get("score_rowstat2" if dominant == "score_rowstat" else "score_colmax3", {})
+        if sq.get("SQ_INSTS_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
+            clk_ghz = 2.35
+            cyc = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"]
+            bound_us = sq["SQ_INSTS_VALU"] * cyc / 1024 / (clk_ghz * 1e3)
+            dom_ms = a_ms if dominant == "score_rowstat" else b_ms
+            roofline["valu_issue_bound"] = {
+                "valu_wave_instructions_per_launch": sq["SQ_INSTS_VALU"], "mfma_instructions_per_launch": sq.get("SQ_INSTS_MFMA"),
+                "cycles_per_valu_instruction": cyc, "simds": 1024, "clock_ghz_under_load": clk_ghz, "bound_us": bound_us,
+                "measured_us": dom_ms * 1e3, "frac": bound_us / (dom_ms * 1e3),
+                "note": "counters from a separate rocprofv3 --pmc pass at this geometry (file read); the kernel is bound by VALU issue, "
+                        "the MFMA fraction above is reported because SURVEY 8(d) prices the stage in QK^T flops"}
         workload = (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, "
                     f"{len(chunks)} scoring chunks of {args.chunk}, ratio {ratio}: score + select + compact; "
                     "one independent context per GPU")

@@ -4,6 +4,7 @@
 
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -89,24 +90,22 @@ static void prof_collect() {
 // ---- tuning knobs --------------------------------------------------------------------------------------------------------
 namespace kvz {
 static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd"};
-// attn_items: work items the key ranges of a decode call are cut into (128 / 192 / 256 / 384 measured in round 2,
-//   profiles/r2_attn_items.txt: 192 is best or within 1 % of the best on uniform, AdaKV-ragged and head-level caches);
+// attn_items: work items the key ranges of a decode call are cut into; 0 (default) = 256 - Hkv, see kvz_attn.hip:attn_items
+//   (round 2 measured 128 / 192 / 256 / 384 on an infinity-cache-resident probe, profiles/r2_attn_items.txt; round 4 on cold HBM);
 // flash_min_rows: query rows per head above which the multi-row kernels take over from the split-key decode kernel;
 // flash2_min_blocks: (head, 256-row tile) blocks from which the 32-row dense forward is used instead of the 16-row one;
 // flash2_xcd: 1 = XCD-aware block order of the 32-row dense forward (a head's row tiles on 8 / Hkv XCDs), 0 = head-major grid.
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-static const int g_tune_default[TUNE_COUNT] = {192, 64, 128, 1};
-static int g_tune[TUNE_COUNT] = {192, 64, 128, 1};
-int tunable(Tunable t) { return g_tune[t]; }
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1};
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}};   // (atomic: a probe may flip a knob while another thread launches)
+int tunable(Tunable t) { return g_tune[t].load(std::memory_order_relaxed); }
 }  // namespace kvz
 extern "C" int kvz_debug_set_tunable(const char* name, int value) {
     KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_set_tunable: null name");
     for (int i = 0; i < kvz::TUNE_COUNT; ++i)
         if (strcmp(name, kvz::g_tune_name[i]) == 0) {
-            const int prev = kvz::g_tune[i];
             // (value <= 0 restores the default; the on / off knob flash2_xcd takes 0 as "off" and negative values as "default")
-            kvz::g_tune[i] = (value > 0 || (i == kvz::TUNE_FLASH2_XCD && value == 0)) ? value : kvz::g_tune_default[i];
-            return prev;
+            return kvz::g_tune[i].exchange((value > 0 || (i == kvz::TUNE_FLASH2_XCD && value == 0)) ? value : kvz::g_tune_default[i]);
         }
     kvz::set_error("kvz_debug_set_tunable: unknown knob '%s'", name);
     return KVZ_EINVAL;
@@ -149,6 +148,8 @@ namespace kvz {
 struct AsyncCtx {
     std::vector<hipEvent_t> ready, done;
     std::vector<char> pending;
+    std::mutex mu;   // the per-slot state (pending flags, event records) is touched under this lock: a context may be driven from
+                     // several host threads (ctypes releases the GIL); stream ORDER between their calls stays the callers' business
 };
 static std::mutex g_async_mu;
 static std::vector<AsyncCtx*> g_async;
@@ -198,6 +199,7 @@ extern "C" int kvz_async_wait(int handle, int slot, kvz_stream_t stream) {
     KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_async_wait: bad handle %d", handle);
     KVZ_REQUIRE(slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_async_wait: bad slot %d", slot);
     const int lo = slot < 0 ? 0 : slot, hi = slot < 0 ? (int)c->pending.size() : slot + 1;
+    std::lock_guard<std::mutex> lk(c->mu);
     for (int i = lo; i < hi; ++i)
         if (c->pending[i]) {
             if (hipStreamWaitEvent((hipStream_t)stream, c->done[i], 0) != hipSuccess) {
@@ -235,6 +237,7 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
     kvz::AsyncCtx* c = kvz::async_get(handle);
     KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_chunk_async: bad handle %d", handle);
     KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_chunk_async: bad slot %d", slot);
+    std::lock_guard<std::mutex> lk(c->mu);
     if (side != caller) {
         if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
             hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess) {
@@ -283,6 +286,7 @@ extern "C" int kvz_score_from_stats_async_log(int handle, int slot, kvz_stream_t
     kvz::AsyncCtx* c = kvz::async_get(handle);
     KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_from_stats_async_log: bad handle %d", handle);
     KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_from_stats_async_log: bad slot %d", slot);
+    std::lock_guard<std::mutex> lk(c->mu);
     if (side != caller) {
         if (hipEventRecord(c->ready[slot], (hipStream_t)caller) != hipSuccess ||
             hipStreamWaitEvent((hipStream_t)side, c->ready[slot], 0) != hipSuccess) {

@@ -161,26 +161,20 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
         }
     };
     u32x4 kraw[2][C::KK], vraw[C::VLOADS], knext[2][C::KK], vnext[C::VLOADS];
-    {
-        const int tfirst = c0 + wave * AT_KT;
-        if (tfirst < c1) load_tile(kraw, vraw, tfirst);
-    }
-#pragma unroll 1
-    for (int t0 = c0 + wave * AT_KT; t0 < c1; t0 += AT_WAVES * AT_KT) {
-        const int tn = t0 + AT_WAVES * AT_KT;
-        if (tn < c1) load_tile(knext, vnext, tn);
+    // one 32-key tile of this wave: S^T = K.Q^T, online softmax, V through the wave's LDS tile, O^T += V^T.P^T
+    auto compute_tile = [&](const u32x4 (&kr)[2][C::KK], const u32x4 (&vr)[C::VLOADS], int t0) __attribute__((always_inline)) {
         f4 s[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             s[sub] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk)
-                s[sub] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, kraw[sub][kk]), qf[kk], s[sub]);
+                s[sub] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, kr[sub][kk]), qf[kk], s[sub]);
         }
 #pragma unroll
         for (int it = 0; it < C::VLOADS; ++it) {
             const int c = it * WAVE + lane;
-            *reinterpret_cast<u32x4*>(wl + (c / C::CPR) * C::VSTRIDE + (c % C::CPR) * 16) = vraw[it];
+            *reinterpret_cast<u32x4*>(wl + (c / C::CPR) * C::VSTRIDE + (c % C::CPR) * 16) = vr[it];
         }
         float sv[8];
         float tmax = -INFINITY;
@@ -219,7 +213,21 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
             s8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             o[db] = HalfTraits<T>::mfma(__builtin_bit_cast(v8, both), pb, o[db]);
         }
-        if (tn < c1) {
+    };
+    // The wave's tiles, one requested AHEAD of the one being computed.  Round 4: the steady-state loop issues the next tile's loads
+    // UNCONDITIONALLY and the last tile is computed after the loop.  With the request inside `if (tn < c1)` the compiler has to place
+    // waits that are right on both paths - s_waitcnt vmcnt(7) .. vmcnt(0) before the V rows of the CURRENT tile go to LDS - which
+    // drains the tile that has just been requested in the middle of every iteration: no load was ever in flight while a wave
+    // computed, and the kernel ran at 21 us where the bare read stream takes 12.5 (profiles/r4_probe_stream.txt).
+    const int t_first = c0 + wave * AT_KT;
+    constexpr int T_STEP = AT_WAVES * AT_KT;
+    if (t_first < c1) {
+        load_tile(kraw, vraw, t_first);
+        int t0 = t_first;
+#pragma unroll 1
+        for (; t0 + T_STEP < c1; t0 += T_STEP) {
+            load_tile(knext, vnext, t0 + T_STEP);
+            compute_tile(kraw, vraw, t0);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
 #pragma unroll
             for (int it = 0; it < C::VLOADS; ++it) vraw[it] = vnext[it];
         }
+        compute_tile(kraw, vraw, t0);
     }
 
     // ---- merge the 8 waves of the block through LDS (each wave writes only its own region) ----------
@@ -390,11 +399,19 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine2_kernel(const 
 
 __global__ void add_i32_kernel(int32_t* p, int delta) { *p += delta; }
 
-static inline int attn_items() { return tunable(TUNE_ATTN_ITEMS); }
+// work items a decode call is cut into.  Default (knob 0): 256 - Hkv, the most that can never exceed one block per CU (every head
+// rounds its item count up, so a call has at most target + Hkv items; one item beyond 256 costs a second round of blocks: 25 -> 34 us
+// per layer, profiles/r4_decode_cold_probe.txt).  Round 2 had settled on 192 with a probe whose single 80-MB cache lived in the
+// infinity cache; streaming a whole model's caches from cold HBM, 252 items are 3 % faster than 192.
+static inline int attn_items(int Hkv) {
+    const int t = tunable(TUNE_ATTN_ITEMS);
+    if (t > 0) return t;
+    return Hkv < 192 ? 256 - Hkv : 64;
+}
 static inline size_t align256a(size_t x) { return (x + 255) & ~(size_t)255; }
 struct AttnWs { uint32_t* counters; float* part_ml; float* part_o; size_t bytes; };
 static inline AttnWs attn_ws(void* ws, int Hkv, int n_rtiles, int D) {
-    const size_t items = (size_t)attn_items() + Hkv;
+    const size_t items = (size_t)attn_items(Hkv) + Hkv;
     AttnWs w;
     char* p = reinterpret_cast<char*>(ws);
     w.counters = reinterpret_cast<uint32_t*>(p);
@@ -414,7 +431,7 @@ static int launch_attn(const void* q, const void* k, const void* v, const int32_
                        int64_t kn_stride = 0, int64_t vn_stride = 0) {
     const int n_rtiles = (q_len * G + AT_RT - 1) / AT_RT;
     const AttnWs w = attn_ws(ws, Hkv, n_rtiles, D);
-    const int target = attn_items();
+    const int target = attn_items(Hkv);
     HeadMeta hm;
     const bool host = meta_host != nullptr && Hkv <= AT_MAXH;
     if (host)

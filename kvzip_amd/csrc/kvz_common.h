@@ -68,6 +68,24 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
 constexpr int SEL_HI_BINS = 2048, SEL_LO_BINS = 32;
 constexpr size_t SEL_WS_WORDS = SEL_HI_BINS + SEL_LO_BINS + 4;
 
+// Streaming read of `nvec` 16-byte vectors by a whole grid (x dimension), U loads in flight per thread before the first one is
+// consumed: a grid-stride loop with ONE dependent 16-byte load per iteration keeps ~8 KB per CU in flight and runs at 1.4 TB/s on
+// an L2 / MALL-resident input (profiles/r4_select.txt); f(i, v) is called once per vector.
+typedef uint32_t kvz_u32x4 __attribute__((ext_vector_type(4)));
+template <int U, typename F>
+__device__ static inline void stream_vec16(const kvz_u32x4* __restrict__ src, int64_t nvec, F&& f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < nvec; i += U * stride) {
+        kvz_u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) f(i + u * stride, v[u]);
+    }
+    for (; i < nvec; i += stride) f(i, src[i]);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- half / bf16 bit helpers ------------------------------------------------------------

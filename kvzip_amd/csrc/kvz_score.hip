@@ -1242,8 +1242,8 @@ __global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint
     auto conv = [](uint32_t b) -> uint32_t { return bits16<T>((T)(b == 0u ? __builtin_nanf("") : expf(__builtin_bit_cast(float, b)))); };
     const int64_t nvec = n >> 3;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
-        const u32x4 l0 = reinterpret_cast<const u32x4*>(log)[2 * i], l1 = reinterpret_cast<const u32x4*>(log)[2 * i + 1];
+    constexpr int U = 2;   // 8-element groups in flight per thread (4 x 16-byte loads: one dependent load per iteration runs at 1.4 TB/s)
+    auto one = [&](int64_t i, const u32x4& l0, const u32x4& l1) {
         const uint32_t lw[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         bool any_empty = false;
 #pragma unroll
@@ -1259,7 +1259,17 @@ __global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint
         }
         const u32x4 w = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
         reinterpret_cast<u32x4*>(out)[i] = w;
+    };
+    const u32x4* lv = reinterpret_cast<const u32x4*>(log);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < nvec; i += U * stride) {
+        u32x4 a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a0[u] = lv[2 * (i + u * stride)]; a1[u] = lv[2 * (i + u * stride) + 1]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(i + u * stride, a0[u], a1[u]);
     }
+    for (; i < nvec; i += stride) one(i, lv[2 * i], lv[2 * i + 1]);
     if (blockIdx.x == 0) {  // tail (< 8 elements)
         for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 256) {
             const uint32_t b = log[i];

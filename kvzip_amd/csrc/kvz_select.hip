@@ -19,9 +19,10 @@ namespace kvz {
 constexpr int HI_BINS = SEL_HI_BINS;  // top 11 bits of the order key
 constexpr int LO_BINS = SEL_LO_BINS;  // low 5 bits
 constexpr int SEL_THREADS = 256;
+constexpr int SEL_UNROLL = 4;         // 16-byte loads a thread keeps in flight in the streaming passes
 constexpr size_t SELECT_WS_WORDS = SEL_WS_WORDS;
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef kvz_u32x4 u32x4;
 
 __device__ static inline void unpack8(const u32x4& v, uint32_t (&bits)[8]) {
 #pragma unroll
@@ -39,15 +40,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_hi_kernel(const uint1
     __syncthreads();
 
     const int64_t nvec = n >> 3;
-    const u32x4* sv = reinterpret_cast<const u32x4*>(scores);
-    const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < nvec; i += stride) {
-        u32x4 v = sv[i];
+    stream_vec16<SEL_UNROLL>(reinterpret_cast<const u32x4*>(scores), nvec, [&](int64_t, const u32x4& v) {
         uint32_t b[8];
         unpack8(v, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(&lh[order_key16(b[j]) >> 5], 1u);
-    }
+    });
     // tail (< 8 elements) handled by block 0
     if (blockIdx.x == 0) {
         for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += SEL_THREADS)
@@ -134,10 +132,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
     __syncthreads();
 
     const int64_t nvec = n >> 3;
-    const u32x4* sv = reinterpret_cast<const u32x4*>(scores);
-    const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < nvec; i += stride) {
-        u32x4 v = sv[i];
+    stream_vec16<SEL_UNROLL>(reinterpret_cast<const u32x4*>(scores), nvec, [&](int64_t, const u32x4& v) {
         uint32_t b[8];
         unpack8(v, b);
 #pragma unroll
@@ -145,7 +140,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
             uint32_t key = order_key16(b[j]);
             if ((key >> 5) == bin) atomicAdd(&ll[key & 31u], 1u);
         }
-    }
+    });
     if (blockIdx.x == 0) {
         for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += SEL_THREADS) {
             uint32_t key = order_key16(scores[i]);
@@ -183,11 +178,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
     const bool vec_ok = ((row_len & 7) == 0);
     if (vec_ok) {
         const int64_t nvec = row_len >> 3;
-        const u32x4* sv = reinterpret_cast<const u32x4*>(srow);
         uint2* vv = reinterpret_cast<uint2*>(vrow);
-        const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-        for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < nvec; i += stride) {
-            u32x4 v = sv[i];
+        stream_vec16<SEL_UNROLL>(reinterpret_cast<const u32x4*>(srow), nvec, [&](int64_t i, const u32x4& v) {
             uint32_t b[8];
             unpack8(v, b);
             uint32_t m[8];
@@ -200,7 +192,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
             o.x = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
             o.y = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
             vv[i] = o;
-        }
+        });
     } else {
         const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
         for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < row_len; i += stride) {
