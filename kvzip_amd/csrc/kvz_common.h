@@ -75,15 +75,17 @@ typedef uint32_t kvz_u32x4 __attribute__((ext_vector_type(4)));
 template <int U, typename F>
 __device__ static inline void stream_vec16(const kvz_u32x4* __restrict__ src, int64_t nvec, F&& f) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += U * stride) {
         kvz_u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+        for (int u = 0; u < U; ++u) {  // (the last batch re-reads its first vector where it runs past the end: the loads stay unconditional)
+            const int64_t j = i + u * stride;
+            v[u] = src[j < nvec ? j : i];
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) f(i + u * stride, v[u]);
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < nvec) f(i + u * stride, v[u]);
     }
-    for (; i < nvec; i += stride) f(i, src[i]);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

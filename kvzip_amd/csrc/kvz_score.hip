@@ -198,6 +198,9 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 //    one 32-key block ahead into a second register set (a prefetch into the registers the chain in flight still
 //    reads stalls the in-order issue), and the hand-over barrier sits right after the LAST matrix chain of a tile
 //    has been issued, not after its epilogue.  The tile stream runs across item boundaries.
+#ifndef KVZ_PA_FAR_BASE
+#define KVZ_PA_FAR_BASE 1
+#endif
 constexpr int PA_WAVES = 8;
 constexpr int PA_RG = 1;                        // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
@@ -582,9 +585,20 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         }
         return w;
     };
-    // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates
+    // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates -
+    // up to 64 KiB: the third buffer of the ring at D = 128 lies beyond the 16-bit offset field and is read through a second set of
+    // bases (one address add per fragment register and read otherwise: 8 VALU instructions per 32-key block of that buffer)
+    constexpr bool FAR_BASE = KVZ_PA_FAR_BASE && RING * C::TILE_BYTES > 65536;
+    FragAddr<D> fa_far;
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) {
+        fa_far.a[kk] = fa0.a[kk] + 65536u;
+        if (FAR_BASE) asm volatile("" : "+v"(fa_far.a[kk]));
+    }
     auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
-        frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
+        constexpr int off = decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES;
+        if constexpr (FAR_BASE && off >= 65536) frag_load<D>(fr, fa_far, off - 65536);
+        else frag_load<D>(fr, fa0, off);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -989,8 +1003,20 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
     };
     FragAddr<D> fa0;
     fa0.init(lds, l31, half);
+    // the ds_read offset field holds 16 bits and the ring spans 96 KiB at D = 128: reads of the third buffer cost one address add per
+    // fragment register (8 VALU instructions per 32-row block, found in the ISA: v_or_b32 in front of every ds_read_b128 of buffer 2).
+    // This kernel has the registers for a second set of bases (191 of 256): buffers at or beyond 64 KiB are read through it.
+    constexpr bool FAR_BASE = RING * C::TILE_BYTES > 65536;
+    FragAddr<D> fa_far;
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) {
+        fa_far.a[kk] = fa0.a[kk] + 65536u;
+        asm volatile("" : "+v"(fa_far.a[kk]));   // (opaque: the compiler would fold it back into fa0 + constant and re-add per read)
+    }
     auto load_frags = [&](u32x4 (&fr)[C::KK], auto b_tag, auto kb_tag) __attribute__((always_inline)) {
-        frag_load<D>(fr, fa0, decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES);
+        constexpr int off = decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES;
+        if constexpr (FAR_BASE && off >= 65536) frag_load<D>(fr, fa_far, off - 65536);
+        else frag_load<D>(fr, fa0, off);
     };
 
     float best[PB_RG][16], hold[PB_RG][16];

@@ -19,7 +19,7 @@ namespace kvz {
 constexpr int HI_BINS = SEL_HI_BINS;  // top 11 bits of the order key
 constexpr int LO_BINS = SEL_LO_BINS;  // low 5 bits
 constexpr int SEL_THREADS = 256;
-constexpr int SEL_UNROLL = 4;         // 16-byte loads a thread keeps in flight in the streaming passes
+constexpr int SEL_UNROLL = 8;         // 16-byte loads a thread keeps in flight in the streaming passes
 constexpr size_t SELECT_WS_WORDS = SEL_WS_WORDS;
 
 typedef kvz_u32x4 u32x4;
