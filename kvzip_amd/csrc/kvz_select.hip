@@ -58,61 +58,46 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_hi_kernel(const uint1
     }
 }
 
-// Block-wide search of a descending cumulative histogram: finds the bin `b` and the residual rank
-// `r` such that (number of elements in bins > b) <= idx < that + hist[b].  BINS <= 8*SEL_THREADS.
+// Search of a descending cumulative histogram by ONE wave: the bin `b` and the residual rank `r` such that (number of elements in
+// bins > b) <= idx < that + hist[b].  It is the prologue of the streaming launches (round 4: every block locates the bin itself; a
+// block-wide form with ~10 barriers cost a few microseconds in front of a 10-us streaming pass).  Lane l owns the BINS / 64
+// consecutive bins of descending position l*PER .. l*PER+PER-1; 64-bit counts (n may exceed 2^32).  One barrier to publish the result.
 template <int BINS>
-__device__ static inline void find_bin_desc(const uint32_t* hist, uint64_t idx, uint32_t* out_bin,
-                                            uint64_t* out_rank, uint64_t* out_above) {
-    constexpr int PER = (BINS + SEL_THREADS - 1) / SEL_THREADS;
-    __shared__ uint64_t part[SEL_THREADS];
+__device__ static inline void find_bin_wave(const uint32_t* __restrict__ hist, uint64_t idx, uint32_t* out_bin, uint64_t* out_rank) {
+    constexpr int PER = (BINS + 63) / 64;
     __shared__ uint32_t s_bin;
-    __shared__ uint64_t s_rank, s_above;
-    const int t = threadIdx.x;
-    uint32_t loc[PER];
-    uint64_t sum = 0;
+    __shared__ uint64_t s_rank;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        uint32_t loc[PER];
+        uint64_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        int jj = t * PER + j;  // position in DEscending order
-        loc[j] = (jj < BINS) ? hist[BINS - 1 - jj] : 0u;
-        sum += loc[j];
-    }
-    part[t] = sum;
-    if (t == 0) { s_bin = 0; s_rank = 0; s_above = 0; }
-    __syncthreads();
-    // exclusive prefix over threads (SEL_THREADS is small: serial scan by one wave is fine)
-    if (t < 64) {
-        // each lane owns 4 consecutive partials
-        uint64_t a0 = part[4 * t], a1 = part[4 * t + 1], a2 = part[4 * t + 2], a3 = part[4 * t + 3];
-        uint64_t tot = a0 + a1 + a2 + a3;
-        uint64_t inc = tot;
+        for (int j = 0; j < PER; ++j) {
+            const int jj = t * PER + j;  // position in DEscending order
+            loc[j] = (jj < BINS) ? hist[BINS - 1 - jj] : 0u;
+            sum += loc[j];
+        }
+        uint64_t inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint64_t nb = __shfl_up(inc, o, 64);
+            const uint64_t nb = __shfl_up(inc, o, 64);
             if (t >= o) inc += nb;
         }
-        uint64_t ex = inc - tot;
-        part[4 * t] = ex;
-        part[4 * t + 1] = ex + a0;
-        part[4 * t + 2] = ex + a0 + a1;
-        part[4 * t + 3] = ex + a0 + a1 + a2;
-    }
-    __syncthreads();
-    uint64_t above = part[t];
+        uint64_t above = inc - sum;
+        if (idx >= above && idx < above + sum) {   // exactly one lane (idx < total)
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        int jj = t * PER + j;
-        if (jj < BINS && idx >= above && idx < above + loc[j]) {
-            s_bin = (uint32_t)(BINS - 1 - jj);
-            s_rank = idx - above;
-            s_above = above;
+            for (int j = 0; j < PER; ++j) {
+                if (idx >= above && idx < above + loc[j]) {
+                    s_bin = (uint32_t)(BINS - 1 - (t * PER + j));
+                    s_rank = idx - above;
+                }
+                above += loc[j];
+            }
         }
-        above += loc[j];
     }
     __syncthreads();
     *out_bin = s_bin;
     *out_rank = s_rank;
-    *out_above = s_above;
-    __syncthreads();
 }
 
 // ---- pass 2: histogram of the low 5 bits inside the top bin that holds rank idx (every block finds that bin itself) -----------
@@ -122,8 +107,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
                                                                     int64_t rows, unsigned long long* __restrict__ kept_dev) {
     __shared__ uint32_t ll[LO_BINS];
     uint32_t bin;
-    uint64_t rank, above;
-    find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
+    uint64_t rank;
+    find_bin_wave<HI_BINS>(hist_hi, idx, &bin, &rank);
     if (threadIdx.x < LO_BINS) ll[threadIdx.x] = 0;
     // the counters the mask launch adds to (nothing else touches them before it)
     for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; row_counts && i < rows; i += (int64_t)gridDim.x * SEL_THREADS)
@@ -163,9 +148,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
     float* __restrict__ thres_dev, unsigned long long* __restrict__ kept_dev) {
     // the 16-bit key of the threshold: top bin from the first histogram, low bits from the second (every block, redundantly)
     uint32_t bin, lo;
-    uint64_t rank, above, rank2, above2;
-    find_bin_desc<HI_BINS>(hist_hi, idx, &bin, &rank, &above);
-    find_bin_desc<LO_BINS>(hist_lo, rank, &lo, &rank2, &above2);
+    uint64_t rank, rank2;
+    find_bin_wave<HI_BINS>(hist_hi, idx, &bin, &rank);
+    find_bin_wave<LO_BINS>(hist_lo, rank, &lo, &rank2);
     const uint32_t tkey = (bin << 5) | lo;
     const uint32_t tbits = order_key16_inv(tkey);
     const float thres = half_bits_to_float(tbits, dtype);

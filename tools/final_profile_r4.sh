@@ -48,10 +48,11 @@ if [ $part = pmc ]; then
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmcf_$what -o f --output-format csv -- python $R/tools/prof_score.py $what 3 > /dev/null 2>&1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmcw_$what -o w --output-format csv -- python $R/tools/prof_score.py $what 3 > /dev/null 2>&1
   done
+  rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $O/pmc1 -o p1 --output-format csv -- python $R/tools/prof_score.py score 3 > /dev/null 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace -d $O/pmc2 -o p2 --output-format csv -- python $R/tools/prof_score.py score 3 > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmcf_flash -o f --output-format csv -- python $R/tools/prof_score.py flash 2 > /dev/null 2>&1
   cd $R
-  python tools/pmc_summary.py $O/pmcf_score $O/pmcw_score $O/pmcf_attn $O/pmcw_attn $O/pmc2 $O/pmcf_flash > $O/pmc_summary.json 2>&1
+  python tools/pmc_summary.py $O/pmcf_score $O/pmcw_score $O/pmcf_attn $O/pmcw_attn $O/pmc1 $O/pmc2 $O/pmcf_flash > $O/pmc_summary.json 2>&1
   find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +1M -delete
   head -c 1200 $O/pmc_summary.json
 fi
