@@ -1032,39 +1032,66 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
         // as soon as the stationary keys, the first tile and the statistics are there - the second tile is awaited at the first
         // hand-over) ----
         {
-            // two dependent round trips to memory: the unit's partial count, then all of its partials at once
+            // two dependent round trips to memory per batch of rows: the units' partial counts, then all of their partials at once
             const int row_lo = t_begin * SC_TILE, nrows = (t_end - t_begin) * SC_TILE;
             if (threadIdx.x == 0) nan_rows = 0;
             __syncthreads();
             const int64_t rows_total = (int64_t)a.n_kv_heads * a.stats_stride;
             bool bad = false;
             constexpr int MAXS = 4;  // partials fetched in one go (more: the general loop below)
-            for (int idx = threadIdx.x; idx < nrows; idx += NWAVES * 64) {
-                const int r = row_lo + idx;
-                float2 v = make_float2(INFINITY, 0.f);
-                if (r < R) {
-                    const int64_t i = (int64_t)h * a.stats_stride + r;
-                    const int nseg = a.unit_nseg ? a.unit_nseg[(r / a.unit_rows) * a.n_kv_heads + h] : 1;  // (null: statistics already merged)
-                    if (a.max_seg <= MAXS) {
-                        constexpr float L2E = 1.44269504088896340736f;
-                        float2 ps[MAXS];
+            if (a.max_seg <= MAXS) {
+                // Round 4: the rows of a thread in batches of four, every load of a batch issued before the first one is used - ONE
+                // round trip for the four partial counts, ONE for the sixteen partials (a row per loop iteration was two dependent
+                // round trips per row, 3.5 rows per thread: the longest chain of the kernel's prologue)
+                constexpr int RPT = 4;
+                constexpr float L2E = 1.44269504088896340736f;
+                for (int base = 0; base < nrows; base += NWAVES * 64 * RPT) {
+                    int ns[RPT];
+                    int64_t ii[RPT];
 #pragma unroll
-                        for (int sgm = 0; sgm < MAXS; ++sgm) ps[sgm] = a.stats[(int64_t)min(sgm, nseg - 1) * rows_total + i];
-                        float M = -INFINITY;
-#pragma unroll
-                        for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nseg) M = fmaxf(M, ps[sgm].x);
-                        const float ML2 = M * L2E;
-                        float Lp = 0.f;
-#pragma unroll
-                        for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nseg) Lp += ps[sgm].y * __builtin_amdgcn_exp2f(ps[sgm].x * L2E - ML2);
-                        const float delta = __builtin_fmaf(M, L2E, -ML2);
-                        v = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
-                    } else {
-                        v = merge_row_stats(a.stats, rows_total, i, nseg);
+                    for (int u = 0; u < RPT; ++u) {
+                        const int idx = base + u * NWAVES * 64 + (int)threadIdx.x;
+                        const int r = min(row_lo + idx, R - 1);               // (rows beyond R: loads of a valid row, result discarded)
+                        ii[u] = (int64_t)h * a.stats_stride + r;
+                        ns[u] = a.unit_nseg ? a.unit_nseg[(r / a.unit_rows) * a.n_kv_heads + h] : 1;  // (null: statistics already merged)
                     }
-                    bad |= !(v.x == v.x) || !(v.y == v.y);
+                    float2 ps[RPT][MAXS];
+#pragma unroll
+                    for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                        for (int sgm = 0; sgm < MAXS; ++sgm) ps[u][sgm] = a.stats[(int64_t)min(sgm, ns[u] - 1) * rows_total + ii[u]];
+#pragma unroll
+                    for (int u = 0; u < RPT; ++u) {
+                        const int idx = base + u * NWAVES * 64 + (int)threadIdx.x;
+                        if (idx >= nrows) continue;
+                        float2 v = make_float2(INFINITY, 0.f);
+                        if (row_lo + idx < R) {
+                            float M = -INFINITY;
+#pragma unroll
+                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < ns[u]) M = fmaxf(M, ps[u][sgm].x);
+                            const float ML2 = M * L2E;
+                            float Lp = 0.f;
+#pragma unroll
+                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < ns[u]) Lp += ps[u][sgm].y * __builtin_amdgcn_exp2f(ps[u][sgm].x * L2E - ML2);
+                            const float delta = __builtin_fmaf(M, L2E, -ML2);
+                            v = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
+                            bad |= !(v.x == v.x) || !(v.y == v.y);
+                        }
+                        lstat[idx] = v;
+                    }
                 }
-                lstat[idx] = v;
+            } else {
+                for (int idx = threadIdx.x; idx < nrows; idx += NWAVES * 64) {
+                    const int r = row_lo + idx;
+                    float2 v = make_float2(INFINITY, 0.f);
+                    if (r < R) {
+                        const int64_t i = (int64_t)h * a.stats_stride + r;
+                        const int nseg = a.unit_nseg ? a.unit_nseg[(r / a.unit_rows) * a.n_kv_heads + h] : 1;
+                        v = merge_row_stats(a.stats, rows_total, i, nseg);
+                        bad |= !(v.x == v.x) || !(v.y == v.y);
+                    }
+                    lstat[idx] = v;
+                }
             }
             if (bad) atomicOr(&nan_rows, 1);
         }
