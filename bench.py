@@ -244,6 +244,12 @@ def cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores):
 
 def main(argv=None):
     args = parse(argv)
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C stdout of rank 0 (buffered, it lands after the
+    # JSON line when stdout is a file), torch / HIP may warn there as well.  The process's stdout is kept aside for the result line
+    # and file descriptor 1 points at stderr from here on.
+    result_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -596,8 +602,9 @@ def main(argv=None):
             out["parity_sample"] = parity
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
     ranks.close()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
