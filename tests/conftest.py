@@ -124,3 +124,20 @@ def check_attn(case: str, got, want, tol: float, rel: float = 0.0, ulp_of=None):
                      "n": int(err.numel()), "max_abs_want": float(w.abs().max()) if w.numel() else 0.0, "worst_margin": margin}
         json.dump(rec, open(path, "w"), indent=0, sort_keys=True)
     assert (err <= bound).all(), (case, worst)
+
+
+def check_mask_flips(case: str, got_scores, want_scores, got_valid, want_valid, want_thres: float, allowed: int = 0):
+    """End-to-end eviction mask vs the mask of the reference's / oracle's scores.  The mask is an integer function of the scores, so an
+    entry may only flip where a score that is NOT bit-identical sits right at the threshold (the strict > evicts ties,
+    attention/score.py:95-96): every flipped entry must be such a score, at most the worst score deviation away from the threshold -
+    nothing else may ever flip - and their number must not exceed `allowed` (what was measured on MI355X: 0 in every small case).
+    Replaces the Hamming fractions (1e-3 .. 1e-4) of rounds 1-3."""
+    d = ulp_diff(got_scores, want_scores).reshape(-1)
+    flips = (got_valid.reshape(-1).cpu() != want_valid.reshape(-1).cpu())
+    ham = int(flips.sum())
+    tb = torch.tensor([want_thres]).to(want_scores.dtype)
+    near = (d > 0) & (ulp_diff(want_scores.reshape(-1), tb.expand(d.numel())) <= max(int(d.max()), 1))
+    print(f"\nMASK {case}: Hamming distance {ham} of {d.numel()} (allowed {allowed}); non-identical scores at the threshold: {int(near.sum())}")
+    assert int((flips & ~near).sum()) == 0, (case, "a mask entry flipped although its score equals the expected one or lies away from the threshold")
+    assert ham <= allowed, (case, ham)
+    return ham

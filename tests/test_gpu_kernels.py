@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import kvzip_oracle as orc
-from conftest import ROOT, check_attn, check_score_parity, from_bits, load_golden, to_bits, ulp_diff
+from conftest import ROOT, check_attn, check_mask_flips, check_score_parity, from_bits, load_golden, to_bits, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -526,11 +526,9 @@ def test_score_then_select_end_to_end_hamming():
     k = torch.randn(1, Hkv, klen, D, generator=g).half()
     want = orc.get_score(q, k, sink, sink, sink + N)
     got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, sink, sink + N)
-    v_ref, _ = orc.threshold(want, 0.3)
+    v_ref, t_ref = orc.threshold(want, 0.3)
     v_hip, _, _, _ = ops().select_threshold(got, 0.3)
-    ham = float((v_ref != v_hip.cpu()).float().mean())
-    print(f"end-to-end mask Hamming distance: {ham:.2e}")
-    assert ham <= 1e-3  # measured 0 of 1024 on MI355X (gpurun call r2c23); one flipped entry is allowed
+    check_mask_flips("score_then_select", got.cpu(), want, v_hip, v_ref, t_ref, allowed=0)   # measured 0 of 1024 in every round
     # and the contract that matters: on the ORACLE's scores the HIP mask is bit-exact
     v_hip2, _, _, _ = ops().select_threshold(want.to(DEV), 0.3)
     assert torch.equal(v_hip2.cpu(), v_ref)
@@ -550,21 +548,19 @@ def test_score_chunk_headline_shape_parity_distribution(dtype):
     got = ops().score_chunk(q.to(DEV), k.to(DEV), sink, sink, sink + m).cpu()
     d = ulp_diff(got, want)
     exact, within1, worst = float((d == 0).float().mean()), float((d <= 1).float().mean()), int(d.max())
-    v_ref, _ = orc.threshold(want.unsqueeze(0), 0.3)
-    v_hip, _ = orc.threshold(got.unsqueeze(0), 0.3)
-    ham = float((v_ref != v_hip).float().mean())
-    print(f"headline shape {dtype}: {exact:.5f} bit-identical, {within1:.5f} within 1 half-ulp, worst {worst}, "
-          f"mask Hamming @0.3 {ham:.2e} of {d.numel()} scores")
+    v_ref, t_ref = orc.threshold(want.unsqueeze(0), 0.3)
+    v_hip, t_hip = orc.threshold(got.unsqueeze(0), 0.3)
+    print(f"headline shape {dtype}: {exact:.5f} bit-identical, {within1:.5f} within 1 half-ulp, worst {worst}")
     check_score_parity(f"headline/{dtype}", got, want)
     assert exact >= HEADLINE_EXACT[dtype] and within1 >= 0.9997 and worst <= 4
-    assert ham <= HEADLINE_HAMMING[dtype]
+    assert t_hip == t_ref
+    check_mask_flips(f"headline/{dtype}", got, want, v_hip, v_ref, t_ref, allowed=0)   # measured 0 of 8000 in rounds 2-4, both dtypes
 
 
 # measured on MI355X with the round-2 kernels (profiles/r2_parity_headline.txt): fp16 99.937 % bit-identical / 99.988 % within one
 # half-ulp / worst 2, bf16 99.988 % / 100 % / worst 1, mask Hamming distance 0 of 8000 for both.  The bounds are the measured
-# non-identical fractions with a margin of 2x; the Hamming bound allows two flipped entries.
+# non-identical fractions with a margin of 2x; the mask: threshold equal, no flipped entry (round 4; conftest.check_mask_flips).
 HEADLINE_EXACT = {torch.float16: 0.9987, torch.bfloat16: 0.99975}
-HEADLINE_HAMMING = {torch.float16: 2.5e-4, torch.bfloat16: 2.5e-4}
 
 
 # ------------------------------------------------------------------------------------------------
