@@ -65,6 +65,8 @@ def parse(argv=None):
                          "bracketed by hipEvents (kernel durations for the roofline; the GPU is idle at a step's start, nothing is "
                          "drained); all other calls overlap on the side streams")
     ap.add_argument("--unfused-update", action="store_true", help="update and _get_score as two library calls")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="set a tuning knob of the library before the run (kvz_debug_set_tunable: measurement only, e.g. pb_variant=1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group even with one GPU and push the result gather and the max-over-ranks "
                          "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
@@ -260,6 +262,9 @@ def main(argv=None):
     from kvzip_amd.dist import backend_version
     from kvzip_amd.kvcache import EvictCache
     lib = _lib.load()
+    for kv_ in args.tune:
+        name, val = kv_.split("=")
+        assert lib.kvz_debug_set_tunable(name.encode(), int(val)) >= 0, f"unknown knob {name}"
 
     L, H, Hkv, D = GEOM[args.model]
     dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
@@ -587,6 +592,7 @@ def main(argv=None):
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
             "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,
             "update_score_fused": not args.unfused_update,
+            "tune": args.tune,
         },
         "roofline": roofline,
         "roofline_stages": stages,
