@@ -49,7 +49,7 @@ struct ProfScope {
 };
 
 // ---- tuning knobs with a test hook (kvz_debug_set_tunable; no environment variables inside the library) ----
-enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_FLASH2_XCD = 3, TUNE_COUNT = 4 };
+enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_FLASH2_XCD = 3, TUNE_SEL_BLOCKS = 4, TUNE_EMIT_BLOCKS = 5, TUNE_COUNT = 6 };
 int tunable(Tunable t);
 
 // exact-reciprocal constant of the scoring rounding chain (kvz_score.hip): half(x * r) == half(x / sqrt(D)) for every 16-bit x, or 0

@@ -1287,14 +1287,14 @@ __global__ void score_finalize_log_kernel(const uint32_t* __restrict__ log, int6
 // never scored contribute the value `out` already holds): the first pass of the global-threshold selection (kvz_select.hip) rides
 // on the launch that streams all scores anyway.  LDS-privatised histogram, one global atomic per non-empty bin and block.
 template <typename T>
-__global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint32_t* __restrict__ log, int64_t n, T* __restrict__ out,
+__global__ __launch_bounds__(1024) void score_finalize_log_hist_kernel(const uint32_t* __restrict__ log, int64_t n, T* __restrict__ out,
                                                                      uint32_t* __restrict__ hist_hi) {
     __shared__ uint32_t lh[SEL_HI_BINS];
-    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 1024) lh[i] = 0;
     __syncthreads();
     auto conv = [](uint32_t b) -> uint32_t { return bits16<T>((T)(b == 0u ? __builtin_nanf("") : expf(__builtin_bit_cast(float, b)))); };
     const int64_t nvec = n >> 3;
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
     constexpr int U = 2;   // 8-element groups in flight per thread (4 x 16-byte loads: one dependent load per iteration runs at 1.4 TB/s)
     auto one = [&](int64_t i, const u32x4& l0, const u32x4& l1) {
         const uint32_t lw[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint
         reinterpret_cast<u32x4*>(out)[i] = w;
     };
     const u32x4* lv = reinterpret_cast<const u32x4*>(log);
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     for (; i + (U - 1) * stride < nvec; i += U * stride) {
         u32x4 a0[U], a1[U];
 #pragma unroll
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint
     }
     for (; i < nvec; i += stride) one(i, lv[2 * i], lv[2 * i + 1]);
     if (blockIdx.x == 0) {  // tail (< 8 elements)
-        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 256) {
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 1024) {
             const uint32_t b = log[i];
             uint32_t v = bits16<T>(out[i]);
             if (b != SC_LOG_EMPTY) {
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void score_finalize_log_hist_kernel(const uint
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 256) {
+    for (int i = threadIdx.x; i < SEL_HI_BINS; i += 1024) {
         const uint32_t c = lh[i];
         if (c) atomicAdd(&hist_hi[i], c);
     }
@@ -1582,13 +1582,13 @@ extern "C" int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void*
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(hipMemsetAsync(select_ws, 0, SEL_WS_WORDS * sizeof(uint32_t), stream) == hipSuccess, KVZ_ELAUNCH,
                 "kvz_score_finalize_log_hist: hipMemsetAsync failed");
-    int blocks = (int)(((n + 7) / 8 + 255) / 256);
-    if (blocks > 512) blocks = 512;  // 2 per CU: every block flushes its non-empty bins with global atomics
+    int blocks = (int)(((n + 7) / 8 + 1023) / 1024);
+    if (blocks > 256) blocks = 256;  // one 1024-thread block per CU: every block flushes its non-empty bins with global atomics (kvz_select.hip)
     if (blocks < 1) blocks = 1;
     uint32_t* hist = reinterpret_cast<uint32_t*>(select_ws);
     ProfScope ps("score_finalize_log", stream);
-    if (dtype == KVZ_F16) hipLaunchKernelGGL((score_finalize_log_hist_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, log, n, reinterpret_cast<_Float16*>(out), hist);
-    else hipLaunchKernelGGL((score_finalize_log_hist_kernel<__bf16>), dim3(blocks), dim3(256), 0, stream, log, n, reinterpret_cast<__bf16*>(out), hist);
+    if (dtype == KVZ_F16) hipLaunchKernelGGL((score_finalize_log_hist_kernel<_Float16>), dim3(blocks), dim3(1024), 0, stream, log, n, reinterpret_cast<_Float16*>(out), hist);
+    else hipLaunchKernelGGL((score_finalize_log_hist_kernel<__bf16>), dim3(blocks), dim3(1024), 0, stream, log, n, reinterpret_cast<__bf16*>(out), hist);
     KVZ_CHECK_LAUNCH("score_finalize_log_hist_kernel");
     return KVZ_OK;
 }

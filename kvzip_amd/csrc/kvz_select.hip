@@ -18,7 +18,10 @@ namespace kvz {
 
 constexpr int HI_BINS = SEL_HI_BINS;  // top 11 bits of the order key
 constexpr int LO_BINS = SEL_LO_BINS;  // low 5 bits
-constexpr int SEL_THREADS = 256;
+constexpr int SEL_THREADS = 256;        // row maximum
+constexpr int HIST_THREADS = 1024;      // histogram and mask passes: one big block per CU - every block ends with one global atomic per non-empty
+                                        // bin, and those serialise on a few hundred addresses: the three passes took 51 / 58 / 78 /
+                                        // 131 / 224 us with 256 / 512 / 1024 / 2048 / 4096 blocks of 256 threads (profiles/r4_select.txt)
 constexpr int SEL_UNROLL = 8;         // 16-byte loads a thread keeps in flight in the streaming passes
 constexpr size_t SELECT_WS_WORDS = SEL_WS_WORDS;
 
@@ -33,10 +36,10 @@ __device__ static inline void unpack8(const u32x4& v, uint32_t (&bits)[8]) {
 }
 
 // ---- pass 1: histogram of the top 11 key bits ---------------------------------------------
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_hi_kernel(const uint16_t* __restrict__ scores,
+__global__ __launch_bounds__(HIST_THREADS) void select_hist_hi_kernel(const uint16_t* __restrict__ scores,
                                                                     int64_t n, uint32_t* __restrict__ hist_hi) {
     __shared__ uint32_t lh[HI_BINS];
-    for (int i = threadIdx.x; i < HI_BINS; i += SEL_THREADS) lh[i] = 0;
+    for (int i = threadIdx.x; i < HI_BINS; i += HIST_THREADS) lh[i] = 0;
     __syncthreads();
 
     const int64_t nvec = n >> 3;
@@ -48,11 +51,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_hi_kernel(const uint1
     });
     // tail (< 8 elements) handled by block 0
     if (blockIdx.x == 0) {
-        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += SEL_THREADS)
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += HIST_THREADS)
             atomicAdd(&lh[order_key16(scores[i]) >> 5], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HI_BINS; i += SEL_THREADS) {
+    for (int i = threadIdx.x; i < HI_BINS; i += HIST_THREADS) {
         uint32_t c = lh[i];
         if (c) atomicAdd(&hist_hi[i], c);
     }
@@ -101,7 +104,7 @@ __device__ static inline void find_bin_wave(const uint32_t* __restrict__ hist, u
 }
 
 // ---- pass 2: histogram of the low 5 bits inside the top bin that holds rank idx (every block finds that bin itself) -----------
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores, int64_t n, uint64_t idx,
+__global__ __launch_bounds__(HIST_THREADS) void select_hist_lo_kernel(const uint16_t* __restrict__ scores, int64_t n, uint64_t idx,
                                                                     const uint32_t* __restrict__ hist_hi,
                                                                     uint32_t* __restrict__ hist_lo, int32_t* __restrict__ row_counts,
                                                                     int64_t rows, unsigned long long* __restrict__ kept_dev) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
     find_bin_wave<HI_BINS>(hist_hi, idx, &bin, &rank);
     if (threadIdx.x < LO_BINS) ll[threadIdx.x] = 0;
     // the counters the mask launch adds to (nothing else touches them before it)
-    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; row_counts && i < rows; i += (int64_t)gridDim.x * SEL_THREADS)
+    for (int64_t i = (int64_t)blockIdx.x * HIST_THREADS + threadIdx.x; row_counts && i < rows; i += (int64_t)gridDim.x * HIST_THREADS)
         row_counts[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *kept_dev = 0ull;
     __syncthreads();
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
         }
     });
     if (blockIdx.x == 0) {
-        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += SEL_THREADS) {
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += HIST_THREADS) {
             uint32_t key = order_key16(scores[i]);
             if ((key >> 5) == bin) atomicAdd(&ll[key & 31u], 1u);
         }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_lo_kernel(const uint1
 // ---- pass 3: emit valid = score > thres, per-row counts, total kept --------------------------
 // grid = (blocks_per_row, rows) when row_counts != nullptr, each block covering a slice of ONE row;
 // otherwise rows == 1 and row_len == n.
-__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
+__global__ __launch_bounds__(HIST_THREADS) void select_emit_kernel(
     const uint16_t* __restrict__ scores, int64_t row_len, int dtype, uint64_t idx, const uint32_t* __restrict__ hist_hi,
     const uint32_t* __restrict__ hist_lo, uint8_t* __restrict__ valid_out, int32_t* __restrict__ row_counts,
     float* __restrict__ thres_dev, unsigned long long* __restrict__ kept_dev) {
@@ -179,22 +182,22 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(
             vv[i] = o;
         });
     } else {
-        const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-        for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < row_len; i += stride) {
+        const int64_t stride = (int64_t)gridDim.x * HIST_THREADS;
+        for (int64_t i = (int64_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < row_len; i += stride) {
             uint32_t mm = (half_bits_to_float(srow[i], dtype) > thres) ? 1u : 0u;
             cnt += (int)mm;
             vrow[i] = (uint8_t)mm;
         }
     }
     // block reduction of cnt -> one atomic per block
-    __shared__ int wsum[SEL_THREADS / WAVE];
+    __shared__ int wsum[HIST_THREADS / WAVE];
     int w = wave_reduce_sum(cnt);
     if (lane_id() == 0) wsum[threadIdx.x >> 6] = w;
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
-        for (int i = 0; i < SEL_THREADS / WAVE; ++i) tot += wsum[i];
+        for (int i = 0; i < HIST_THREADS / WAVE; ++i) tot += wsum[i];
         if (tot) {
             if (row_counts) atomicAdd(&row_counts[row], tot);
             atomicAdd(kept_dev, (unsigned long long)tot);
@@ -453,27 +456,28 @@ static int select_threshold_impl(const void* scores, int64_t n, double ratio, in
     if (!prehist) (void)hipMemsetAsync(ws, 0, SELECT_WS_WORDS * sizeof(uint32_t), stream);
 
     const int64_t nvec = (n + 7) >> 3;
-    int blocks = (int)((nvec + SEL_THREADS - 1) / SEL_THREADS);
-    if (blocks > 512) blocks = 512;  // 2 per CU: every block flushes its non-empty bins with global atomics
+    int blocks = (int)((nvec + HIST_THREADS - 1) / HIST_THREADS);
+    const int cap = tunable(TUNE_SEL_BLOCKS);
+    if (blocks > cap) blocks = cap;  // (256 = one 1024-thread block per CU: every block flushes its non-empty bins with global atomics)
     if (blocks < 1) blocks = 1;
     const uint16_t* s16 = reinterpret_cast<const uint16_t*>(scores);
     ProfScope ps("select", stream);  // the streaming passes
     if (!prehist) {
-        hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, hist_hi);
+        hipLaunchKernelGGL(select_hist_hi_kernel, dim3(blocks), dim3(HIST_THREADS), 0, stream, s16, n, hist_hi);
         KVZ_CHECK_LAUNCH("select_hist_hi_kernel");
     }
-    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(SEL_THREADS), 0, stream, s16, n, (uint64_t)idx, hist_hi, hist_lo,
+    hipLaunchKernelGGL(select_hist_lo_kernel, dim3(blocks), dim3(HIST_THREADS), 0, stream, s16, n, (uint64_t)idx, hist_hi, hist_lo,
                        row_counts, rows, reinterpret_cast<unsigned long long*>(kept_dev));
     KVZ_CHECK_LAUNCH("select_hist_lo_kernel");
 
     // rows whose start is not 16-byte aligned take the scalar path inside the kernel (row_len % 8 != 0)
     const int64_t per_row_vec = ((row_len & 7) == 0) ? (row_len >> 3) : row_len;
-    int bx = (int)((per_row_vec + SEL_THREADS - 1) / SEL_THREADS);
-    int max_bx = (int)(1024 / rows);
+    int bx = (int)((per_row_vec + HIST_THREADS - 1) / HIST_THREADS);
+    int max_bx = (int)(tunable(TUNE_EMIT_BLOCKS) / rows);
     if (max_bx < 1) max_bx = 1;
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(select_emit_kernel, dim3(bx, (unsigned)rows), dim3(SEL_THREADS), 0, stream, s16, row_len, dtype,
+    hipLaunchKernelGGL(select_emit_kernel, dim3(bx, (unsigned)rows), dim3(HIST_THREADS), 0, stream, s16, row_len, dtype,
                        (uint64_t)idx, hist_hi, hist_lo, valid_out, row_counts, thres_dev,
                        reinterpret_cast<unsigned long long*>(kept_dev));
     KVZ_CHECK_LAUNCH("select_emit_kernel");

@@ -74,8 +74,20 @@ elif what == "compact":
     kept = int(plan.len_k.sum())
     print(f"compact: kept rows {kept}, algorithmic bytes {2 * 2 * kept * D * 2 + L * Hkv * N}")
 elif what == "select":
+    import ctypes as C
+    from kvzip_amd import _lib
+    lib = _lib.load()
     score = (torch.rand(28, 1, Hkv, N, generator=g, device=dev) ** 8).to(dt)
-    for _ in range(iters):
-        ops.select_threshold(score, 0.3, row_len=N)
-    torch.cuda.synchronize()
+    for rnd in range(2):
+        for cap, emit in ((256, 112), (256, 256), (256, 512), (256, 1024), (128, 256), (384, 256)):
+            lib.kvz_debug_set_tunable(b"sel_blocks", cap); lib.kvz_debug_set_tunable(b"emit_blocks", emit)
+            for _ in range(3):
+                ops.select_threshold(score, 0.3, row_len=N)
+            torch.cuda.synchronize(); lib.kvz_prof_reset(); lib.kvz_prof_enable(1)
+            for _ in range(iters):
+                ops.select_threshold(score, 0.3, row_len=N)
+            torch.cuda.synchronize(); lib.kvz_prof_enable(0)
+            t, c = C.c_double(0), C.c_int64(0); lib.kvz_prof_read(b"select", C.byref(t), C.byref(c))
+            print(f"round {rnd} sel_blocks {cap} (1024 threads) emit_blocks {emit}: select (3 launches, plain path) {t.value / max(c.value, 1) * 1e3:.1f} us", flush=True)
+    lib.kvz_debug_set_tunable(b"sel_blocks", -1); lib.kvz_debug_set_tunable(b"emit_blocks", -1)
     print("select: algorithmic bytes", 5 * score.numel())
