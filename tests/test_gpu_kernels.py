@@ -941,3 +941,43 @@ def test_score_chunk_propagates_nan_like_the_reference(poison, deferred):
     assert not torch.isnan(got[0, 1].float()).any()
     d = ulp_diff(got[0, 1], want[0, 1])
     assert (d <= 1).float().mean() >= 0.99 and d.max() <= 16
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_varlen_attn_vs_an_independent_flash_implementation(dtype):
+    """a13 has no reference-held vector (flash-attn 2.7.4.post1 is not in the image).  Besides the CPU restatement, the decode call is
+    anchored on an INDEPENDENT implementation of the same published algorithm that does exist on the GPU box: PyTorch-ROCm's fused
+    flash-attention backend of ``scaled_dot_product_attention`` (AOTriton), forced with ``sdpa_kernel(FLASH_ATTENTION)``.  Per KV head:
+    q_len = 1 (the mask is irrelevant: every key is visible) and a 5-token query with the bottom-right aligned causal mask expressed
+    as "the last 5 rows of a square causal problem" (is_causal over the last 5 keys ++ full visibility of the prefix is what
+    flash-attn's varlen kernel computes).  Both results are 16-bit roundings of the same fp32 value: at most one output step apart."""
+    import torch.nn.functional as F
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    Hkv, G, D = 4, 7, 128
+    lens = [4097, 257, 1500, 33]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    starts, tot = [], 0
+    for ln in lens:
+        starts.append(tot)
+        tot += ln + 7
+    k = torch.randn(tot, D, generator=g, device=DEV).to(dtype)
+    v = torch.randn(tot, D, generator=g, device=DEV).to(dtype)
+    ks = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3
+    for q_len in (1, 5):
+        q = torch.randn(Hkv * q_len, G, D, generator=g, device=DEV).to(dtype)
+        got = ops().varlen_attn(q, k, v, ks, kl, q_len, max(lens)).view(Hkv, q_len, G, D)
+        for h in range(Hkv):
+            kh = k[starts[h]:starts[h] + lens[h]].view(1, 1, lens[h], D).expand(1, G, -1, -1)
+            vh = v[starts[h]:starts[h] + lens[h]].view(1, 1, lens[h], D).expand(1, G, -1, -1)
+            qh = q.view(Hkv, q_len, G, D)[h].permute(1, 0, 2).unsqueeze(0)          # [1, G, q_len, D]
+            with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+                if q_len == 1:
+                    want = F.scaled_dot_product_attention(qh, kh, vh)
+                else:
+                    # bottom-right alignment through a square causal problem: pad the query with lens-q_len leading rows (their
+                    # outputs are discarded); row i of the padded problem sees keys 0..i, i.e. the real row j sees keys 0..j+lens-q_len
+                    pad = torch.zeros(1, G, lens[h] - q_len, D, dtype=dtype, device=DEV)
+                    want = F.scaled_dot_product_attention(torch.cat([pad, qh], dim=2), kh, vh, is_causal=True)[:, :, -q_len:]
+            check_attn(f"vs_torch_flash/{dtype}/q{q_len}/h{h}", got[h].permute(1, 0, 2), want[0], tol, ulp_of=dtype)
