@@ -588,7 +588,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     // fragments of block kb of LDS buffer b: both compile-time, so the buffer and block offsets fold into the ds_read immediates -
     // up to 64 KiB: the third buffer of the ring at D = 128 lies beyond the 16-bit offset field and is read through a second set of
     // bases (one address add per fragment register and read otherwise: 8 VALU instructions per 32-key block of that buffer)
-    constexpr bool FAR_BASE = KVZ_PA_FAR_BASE && RING * C::TILE_BYTES > 65536;
+    // (fp16 only: the bf16 rounding chain needs the 8 registers - with them the kernel sits at 256 VGPRs and spills)
+    constexpr bool FAR_BASE = KVZ_PA_FAR_BASE && std::is_same<T, _Float16>::value && RING * C::TILE_BYTES > 65536;
     FragAddr<D> fa_far;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk) {
@@ -875,6 +876,18 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                 float2* dst = a.stats + ((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + rows.r[g];
                 const float2 val = make_float2(M, Lp);
                 asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+                if (cur.k != u_end) {
+                    // this block walked the unit to its end: the slots beyond its own partial get the NEUTRAL statistic (-inf, 0), so
+                    // that pass B can fetch a fixed number of slots per row without first reading how many the unit has (round 4: one
+                    // dependent round trip less in the prologue of every pass-B block)
+                    const float2 neutral = make_float2(-INFINITY, 0.f);
+                    const int64_t slot_stride = (int64_t)a.n_kv_heads * a.stats_stride;   // (scalar: the next slot of the same row)
+                    float2* dn = dst;
+                    for (int sl = cur.z + 1; sl < a.max_seg; ++sl) {
+                        dn += slot_stride;
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dn), "v"(neutral) : "memory");
+                    }
+                }
             }
         }
         if (cur.k != u_end && threadIdx.x == 0) {
@@ -1040,26 +1053,27 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             bool bad = false;
             constexpr int MAXS = 4;  // partials fetched in one go (more: the general loop below)
             if (a.max_seg <= MAXS) {
-                // Round 4: the rows of a thread in batches of four, every load of a batch issued before the first one is used - ONE
-                // round trip for the four partial counts, ONE for the sixteen partials (a row per loop iteration was two dependent
+                // Round 4: the rows of a thread in batches of four, all sixteen partial loads of a batch issued before the first one
+                // is used - ONE round trip (a row per loop iteration with its unit's partial count fetched first was two dependent
                 // round trips per row, 3.5 rows per thread: the longest chain of the kernel's prologue)
                 constexpr int RPT = 4;
                 constexpr float L2E = 1.44269504088896340736f;
                 for (int base = 0; base < nrows; base += NWAVES * 64 * RPT) {
-                    int ns[RPT];
                     int64_t ii[RPT];
 #pragma unroll
                     for (int u = 0; u < RPT; ++u) {
                         const int idx = base + u * NWAVES * 64 + (int)threadIdx.x;
                         const int r = min(row_lo + idx, R - 1);               // (rows beyond R: loads of a valid row, result discarded)
                         ii[u] = (int64_t)h * a.stats_stride + r;
-                        ns[u] = a.unit_nseg ? a.unit_nseg[(r / a.unit_rows) * a.n_kv_heads + h] : 1;  // (null: statistics already merged)
                     }
+                    // (every row has a.max_seg slots: its unit's partials, then the neutral statistic written by the block that
+                    // finished the unit - no per-unit count to fetch first)
+                    const int nsl = a.max_seg;
                     float2 ps[RPT][MAXS];
 #pragma unroll
                     for (int u = 0; u < RPT; ++u)
 #pragma unroll
-                        for (int sgm = 0; sgm < MAXS; ++sgm) ps[u][sgm] = a.stats[(int64_t)min(sgm, ns[u] - 1) * rows_total + ii[u]];
+                        for (int sgm = 0; sgm < MAXS; ++sgm) ps[u][sgm] = a.stats[(int64_t)min(sgm, nsl - 1) * rows_total + ii[u]];
 #pragma unroll
                     for (int u = 0; u < RPT; ++u) {
                         const int idx = base + u * NWAVES * 64 + (int)threadIdx.x;
@@ -1068,11 +1082,11 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
                         if (row_lo + idx < R) {
                             float M = -INFINITY;
 #pragma unroll
-                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < ns[u]) M = fmaxf(M, ps[u][sgm].x);
+                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nsl) M = fmaxf(M, ps[u][sgm].x);
                             const float ML2 = M * L2E;
                             float Lp = 0.f;
 #pragma unroll
-                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < ns[u]) Lp += ps[u][sgm].y * __builtin_amdgcn_exp2f(ps[u][sgm].x * L2E - ML2);
+                            for (int sgm = 0; sgm < MAXS; ++sgm) if (sgm < nsl) Lp += ps[u][sgm].y * __builtin_amdgcn_exp2f(ps[u][sgm].x * L2E - ML2);
                             const float delta = __builtin_fmaf(M, L2E, -ML2);
                             v = make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
                             bad |= !(v.x == v.x) || !(v.y == v.y);
