@@ -1182,13 +1182,20 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        float2 st_nx[SC_TILE / 32];
+        {
+            const float2* const ls = lstat + l31;   // (first tile of the slice)
+#pragma unroll
+            for (int kb = 0; kb < SC_TILE / 32; ++kb) st_nx[kb] = ls[kb * 32];
+        }
         auto tile_steps = [&](auto b_tag) __attribute__((always_inline)) {
             constexpr int B = decltype(b_tag)::value;
             constexpr int B1 = (B + 1) % RING, B2 = (B + 2) % RING;
-            float2 st[SC_TILE / 32];  // (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of the tile
-            const float2* const ls = lstat + (t - t_begin) * SC_TILE + l31;
+            // (m_r, log l_r) of this lane's query row in each of the four 32-row blocks of the tile: read from LDS one tile AHEAD (last
+            // step of the previous tile; round 4) - read at the top of the tile, the first rounding chain of step 0 waited for them
+            float2 st[SC_TILE / 32];
 #pragma unroll
-            for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = ls[kb * 32];
+            for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = st_nx[kb];
             step(acc[1], acc[0], fr[1], st[0], std::false_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
             step(acc[0], acc[1], fr[0], st[1], std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
             step(acc[1], acc[0], fr[1], st[2], std::false_type{}, [&]() __attribute__((always_inline)) {
@@ -1205,7 +1212,12 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             });
             // (after the last tile the chain issued here is not used)
             step(acc[0], acc[1], fr[0], st[3], std::true_type{}, [&]() __attribute__((always_inline)) {
-                if (t + 1 < t_end) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
+                if (t + 1 < t_end) {
+                    load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
+                    const float2* const ls = lstat + (t + 1 - t_begin) * SC_TILE + l31;
+#pragma unroll
+                    for (int kb = 0; kb < SC_TILE / 32; ++kb) st_nx[kb] = ls[kb * 32];
+                }
             });
         };
         __builtin_amdgcn_sched_barrier(0);
