@@ -343,6 +343,36 @@ def gen_e2e_d128(KVScore):
     np.savez_compressed(os.path.join(OUT, "g9_e2e_d128.npz"), **out)
 
 
+def gen_e2e_llama(KVScore):
+    """G11 (round 4): G9's procedure at BASELINE config C3's head geometry (Llama-3.1-8B: H32 Hkv8 D128, G = 4): 2 layers x 4 scoring
+    chunks, 128 000 scores per dtype under one global threshold, from the REFERENCE's _get_score / _threshold."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_inputs as E
+    geom = E.GEOM_LLAMA
+    out = {}
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        K0, per_chunk = E.make(dt, geom, E.SEED_LLAMA)
+        sc = KVScore()
+        sc.n_heads_kv, sc.dtype, sc.device, sc.n_layers = geom["Hkv"], dt, "cpu", geom["L"]
+        sc.sink = geom["sink"]
+        sc.init_score()
+        for ci, (st, en, q_len) in enumerate(E.chunks(geom)):
+            sc.start_idx, sc.end_idx = st, en
+            for l in range(geom["L"]):
+                q, kr = per_chunk[ci][l]
+                sc._get_score(q, torch.cat([K0[l], kr], dim=2), l)
+        score = torch.stack(sc.score, 0)
+        valid, thres = sc._threshold(sc.score, 0.3)
+        out[f"{tag}/score"] = bits(score)
+        out[f"{tag}/thres"] = np.array([thres], dtype=np.float64)
+        out[f"{tag}/valid"] = np.packbits(valid.numpy().reshape(-1))
+        out[f"{tag}/kept"] = valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32)
+        out[f"{tag}/checksum"] = np.array([E.checksum(K0, per_chunk)], dtype=np.int64)
+        print("g11", tag, "thres", thres, "kept", int(valid.sum()), "of", valid.numel(), flush=True)
+    out["geom"] = np.array([geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g11_e2e_llama.npz"), **out)
+
+
 def gen_e2e_d128_512k(KVScore):
     """G10 (round 4): the same as G9 at 8 layers x 8 scoring chunks = 512 000 scores per dtype under ONE global threshold - 3.5 % of
     the 14.68 M scores of the headline context, produced by the REFERENCE's own _get_score / _threshold (attention/score.py:36-65,
@@ -389,6 +419,9 @@ def main():
     if "--only-e2e-512k" in sys.argv:
         gen_e2e_d128_512k(KVScore)
         return
+    if "--only-e2e-llama" in sys.argv:
+        gen_e2e_llama(KVScore)
+        return
     gen_score(KVScore)
     gen_threshold(KVScore)
     gen_head_scores(KVScore)
@@ -397,6 +430,7 @@ def main():
     gen_templates()
     gen_e2e_d128(KVScore)
     gen_e2e_d128_512k(KVScore)
+    gen_e2e_llama(KVScore)
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print(f"wrote {OUT}: {total / 1e6:.2f} MB")
 

@@ -11,6 +11,9 @@ GEOM = dict(L=2, H=28, Hkv=4, D=128, sink=32, N=8000, chunk=2000)   # Qwen2.5-7B
 # round 4 (tests/golden/g10_e2e_d128_512k.npz): 8 layers x 8 scoring chunks = 512 000 scores under ONE global threshold
 GEOM_512K = dict(L=8, H=28, Hkv=4, D=128, sink=32, N=16000, chunk=2000)
 SEED_512K = 777
+# round 4 (tests/golden/g11_e2e_llama.npz): BASELINE config C3's head geometry (Llama-3.1-8B: H32 Hkv8 D128, G = 4), 2 layers x 4 chunks
+GEOM_LLAMA = dict(L=2, H=32, Hkv=8, D=128, sink=32, N=8000, chunk=2000)
+SEED_LLAMA = 3131
 
 
 def chunks(geom=GEOM):

@@ -84,7 +84,7 @@ def _mask_parity(tag, fixture, geom, seed, case, hamming_allowed):
             print(f"   flipped entry {i}: reference score {float(want[i])!r} (kept {bool(want_valid[i])}), ours {float(got[i])!r}")
     check_score_parity(f"{case}/{tag}", got, want)
     lo_exact, lo_within1, hi_worst, _ = BOUNDS[tag]
-    assert exact >= lo_exact and within1 >= lo_within1 and worst <= hi_worst
+    assert exact >= lo_exact and within1 >= lo_within1 and worst <= hi_worst, (exact, within1, worst)
     assert thres == want_thres, "the global threshold (one order statistic over all layers and chunks) must be the reference's"
     # The mask is an integer function of the scores: given the reference's scores it is reproduced bit for bit (end of this test).  End
     # to end an entry can only flip where a score that is NOT bit-identical to the reference's sits right at the threshold (the strict
@@ -122,6 +122,14 @@ def test_e2e_mask_parity_d128_512k(tag):
     # value); bf16: 0.  That is the number north_star's "bit-exact masks" comes down to at this size: 3.9e-6 of the entries, each one
     # explained by a last-bit difference of the fp32 accumulation order in Q.K^T (the reference's own CPU / GPU builds differ the same way).
     _mask_parity(tag, "g10_e2e_d128_512k.npz", E.GEOM_512K, E.SEED_512K, "e2e_d128_512k", 4 if tag == "f16" else 0)
+
+
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+def test_e2e_mask_parity_llama_geometry(tag):
+    """G11 (round 4): BASELINE config C3's head geometry (Llama-3.1-8B: H32 Hkv8 D128, G = 4 - another row partition of both scoring
+    passes than Qwen2.5-7B's G = 7), 2 layers x 4 chunks = 128 000 scores per dtype from the REFERENCE's own _get_score / _threshold:
+    threshold equal, mask identical."""
+    _mask_parity(tag, "g11_e2e_llama.npz", E.GEOM_LLAMA, E.SEED_LLAMA, "e2e_llama", 0)
 
 
 def test_full_size_masks_do_not_depend_on_streams():

@@ -258,5 +258,28 @@ def test_oracle_threshold_on_e2e_d128_512k_fixture():
         assert np.array_equal(valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32), g[f"{tag}/kept"])
 
 
+def test_oracle_threshold_on_e2e_llama_fixture():
+    """G11 (Llama-3.1-8B head geometry, reference-generated): threshold, mask and kept counts of the reference reproduced by the oracle
+    on the reference's scores, and one (layer, chunk) get_score call reproduced bit for bit (G = 4 path of the restatement)."""
+    import e2e_inputs as E
+    g = load_golden("g11_e2e_llama.npz")
+    geom = E.GEOM_LLAMA
+    assert [geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")] == g["geom"].tolist()
+    for tag, bf in (("f16", False), ("bf16", True)):
+        want = from_bits(g[f"{tag}/score"], bf)
+        valid, thres = orc.threshold([want[i] for i in range(geom["L"])], 0.3)
+        assert thres == float(g[f"{tag}/thres"][0])
+        assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g[f"{tag}/valid"])
+        assert np.array_equal(valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32), g[f"{tag}/kept"])
+    K0, per_chunk = E.make(torch.bfloat16, geom, E.SEED_LLAMA)
+    assert E.checksum(K0, per_chunk) == int(g["bf16/checksum"][0])
+    want = from_bits(g["bf16/score"], True)
+    ci, l = 1, 0
+    st, en, q_len = E.chunks(geom)[ci]
+    q, kr = per_chunk[ci][l]
+    got = orc.get_score(q, torch.cat([K0[l], kr], dim=2), geom["sink"], st, en)
+    assert torch.equal(to_bits_t(got), to_bits_t(want[l][:, :, st - geom["sink"]:en - geom["sink"]]))
+
+
 def to_bits_t(t):
     return t.contiguous().view(torch.int16)
