@@ -1196,8 +1196,14 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
             float2 st[SC_TILE / 32];
 #pragma unroll
             for (int kb = 0; kb < SC_TILE / 32; ++kb) st[kb] = st_nx[kb];
+            // issue priority alternates between the two waves of a SIMD from step to step (the upper half of the block yields in
+            // steps 0 and 2, leads in 1 and 3): -0.6 us per launch, measured same-box against no priorities and the opposite phase
+            const bool young = wave >= NWAVES / 2;
+            if (young) __builtin_amdgcn_s_setprio(0);
             step(acc[1], acc[0], fr[1], st[0], std::false_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
+            if (young) __builtin_amdgcn_s_setprio(1);
             step(acc[0], acc[1], fr[0], st[1], std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+            if (young) __builtin_amdgcn_s_setprio(0);
             step(acc[1], acc[0], fr[1], st[2], std::false_type{}, [&]() __attribute__((always_inline)) {
                 // hand-over: the tile two positions ahead goes into the buffer the previous hand-over freed, its DMA is issued
                 // BEFORE the barrier; the counted wait leaves exactly those pieces in flight
@@ -1211,6 +1217,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
                 if (t + 1 < t_end) load_frags(fr[0], std::integral_constant<int, B1>{}, I0{});
             });
             // (after the last tile the chain issued here is not used)
+            if (young) __builtin_amdgcn_s_setprio(1);
             step(acc[0], acc[1], fr[0], st[3], std::true_type{}, [&]() __attribute__((always_inline)) {
                 if (t + 1 < t_end) {
                     load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
