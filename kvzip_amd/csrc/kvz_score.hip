@@ -252,24 +252,6 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
             "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
             : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
-        return;
-        xa = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a0, a1}, h2v));
-        xb = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a2, a3}, h2v));
-        // second rounding as fp32 product (v_fma_mix_f32 reads the half, half rate) + v_cvt_pk_f16_f32 (two per instruction):
-        // 6.6 instead of 8.1 cycles per logit.  The four products land in the argument registers, which the last four
-        // instructions then overwrite with the exponent arguments (every consumer is >= 2 instructions behind its producer).
-        asm("v_fma_mix_f32 %[g0], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g1], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g2], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g3], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_cvt_pk_f16_f32 %[xa], %[g0], %[g1]\n\t"
-            "v_cvt_pk_f16_f32 %[xb], %[g2], %[g3]\n\t"
-            "v_fma_mix_f32 %[g0], %[xa], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[nm] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[nm] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-            : [xa] "+v"(xa), [xb] "+v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
-            : [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
     } else if constexpr (std::is_same<T, __bf16>::value && FAST) {
         // bf16: there is no mixed-precision fma that reads a bf16 half, so every value goes f32 -> bf16 -> f32 twice.  Written on
         // pairs: v_cvt_pk_bf16_f32 rounds two values per instruction, the way back is a shift / a mask, and the two fp32
@@ -302,7 +284,9 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
 // the four exponentials of a quad and their sums into the two partial sums of the row (one assembly block: left to the
 // compiler the additions are SLP-packed into v_pk_add_f32 with s_nop hazards and all exponentials sink to the end of the
 // step, away from the MFMAs they are meant to cover).  Every v_add is 4 instructions behind its v_exp (transcendental
-// forwarding hazard: 1 wait state).
+// forwarding hazard: 1 wait state).  Hand-placed v_pk_add_f32 on a register pair (two instead of four additions, 78 instead
+// of 89 VALU instructions per block, bit-identical sums) is 1.5 % SLOWER in the scoring loop (round 4, same box): a plain fp32
+// VOP2 issues in 2.5 cycles on this part, the packed form does not, and the pair adds a dependent chain.
 __device__ static inline void quad_sum(const float (&arg)[4], float& ps0, float& ps1) {
     float e0, e1, e2, e3;
     asm("v_exp_f32 %[e0], %[a0]\n\t"
