@@ -89,25 +89,27 @@ static void prof_collect() {
 
 // ---- tuning knobs --------------------------------------------------------------------------------------------------------
 namespace kvz {
-static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "sel_blocks", "emit_blocks"};
+static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "sel_blocks", "emit_blocks", "flash2_split"};
 // attn_items: work items the key ranges of a decode call are cut into; 0 (default) = 256 - Hkv, see kvz_attn.hip:attn_items
 //   (round 2 measured 128 / 192 / 256 / 384 on an infinity-cache-resident probe, profiles/r2_attn_items.txt; round 4 on cold HBM);
 // flash_min_rows: query rows per head above which the multi-row kernels take over from the split-key decode kernel;
 // flash2_min_blocks: (head, 256-row tile) blocks from which the 32-row dense forward is used instead of the 16-row one;
 // flash2_xcd: 1 = XCD-aware block order of the 32-row dense forward (a head's row tiles on 8 / Hkv XCDs), 0 = head-major grid.
+// flash2_split: 1 = the last round of blocks of the 32-row dense forward is split along the keys when that saves a tenth of the rounds
+//   (parts merged by a second launch; needs the workspace), 2 = whenever the units do not fill the last round (tests), 0 = never.
 // sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (256 / 256:
 //   every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 256, 256};
-static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {256}, {256}};   // (atomic: a probe may flip a knob while another thread launches)
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 256, 256, 1};
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {256}, {256}, {1}};   // (atomic: a probe may flip a knob while another thread launches)
 int tunable(Tunable t) { return g_tune[t].load(std::memory_order_relaxed); }
 }  // namespace kvz
 extern "C" int kvz_debug_set_tunable(const char* name, int value) {
     KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_set_tunable: null name");
     for (int i = 0; i < kvz::TUNE_COUNT; ++i)
         if (strcmp(name, kvz::g_tune_name[i]) == 0) {
-            // (value <= 0 restores the default; the on / off knob flash2_xcd takes 0 as "off" and negative values as "default")
-            return kvz::g_tune[i].exchange((value > 0 || (i == kvz::TUNE_FLASH2_XCD && value == 0)) ? value : kvz::g_tune_default[i]);
+            // (value <= 0 restores the default; the on / off knobs flash2_xcd and flash2_split take 0 as "off" and negative values as "default")
+            return kvz::g_tune[i].exchange((value > 0 || ((i == kvz::TUNE_FLASH2_XCD || i == kvz::TUNE_FLASH2_SPLIT) && value == 0)) ? value : kvz::g_tune_default[i]);
         }
     kvz::set_error("kvz_debug_set_tunable: unknown knob '%s'", name);
     return KVZ_EINVAL;

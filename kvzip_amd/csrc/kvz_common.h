@@ -48,8 +48,28 @@ struct ProfScope {
     }
 };
 
+// division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
+// l = ceil(log2 d) (Granlund-Montgomery round-up method, exact for 31-bit numerators).  A 32-bit division costs ~20 instructions;
+// the item switch of pass A had nine of them, executed by all eight waves.
+struct FastDiv {
+    uint32_t d, m, sh;  // sh = l - 1; d == 1 is the identity (m = 0)
+    __host__ __device__ inline int div(int n) const { return m ? (int)(__umulhi_((uint32_t)n, m) >> sh) : n; }
+    __host__ __device__ inline int mod(int n) const { return n - div(n) * (int)d; }
+    __host__ __device__ static inline uint32_t __umulhi_(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+};
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = (uint32_t)d;
+    if (d <= 1) { f.m = 0; f.sh = 0; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    f.m = (uint32_t)((((uint64_t)1 << (31 + l)) + (uint64_t)d - 1) / (uint64_t)d);
+    f.sh = (uint32_t)(l - 1);
+    return f;
+}
+
 // ---- tuning knobs with a test hook (kvz_debug_set_tunable; no environment variables inside the library) ----
-enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_FLASH2_XCD = 3, TUNE_SEL_BLOCKS = 4, TUNE_EMIT_BLOCKS = 5, TUNE_COUNT = 6 };
+enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_FLASH2_XCD = 3, TUNE_SEL_BLOCKS = 4, TUNE_EMIT_BLOCKS = 5, TUNE_FLASH2_SPLIT = 6, TUNE_COUNT = 7 };
 int tunable(Tunable t);
 
 // exact-reciprocal constant of the scoring rounding chain (kvz_score.hip): half(x * r) == half(x / sqrt(D)) for every 16-bit x, or 0
@@ -57,11 +77,12 @@ float score_exact_reciprocal(int D, int dtype);
 
 // the 32-row dense forward (kvz_flash2.hip), reached through kvz_flash_fwd
 bool flash2_takes(int Hkv, int G, int q_len, int D);
+size_t flash2_workspace_bytes(int Hkv, int G, int q_len, int D);
 int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k, const void* v,
                const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int q_len,
                float scale, int causal, int dtype, void* out, int64_t o_stride_head, int64_t o_stride_group, int64_t o_stride_pos,
-               float* lse_out, hipStream_t stream, int win_sink = 0, int win_start = 0, int win_end = 0, float* win_stats = nullptr,
-               int64_t win_stats_head_stride = 0);
+               float* lse_out, void* ws, size_t ws_bytes, hipStream_t stream, int win_sink = 0, int win_start = 0, int win_end = 0,
+               float* win_stats = nullptr, int64_t win_stats_head_stride = 0);
 
 // selection workspace shared by kvz_select.hip and the fused finalize + histogram launch of kvz_score.hip (uint32 words):
 // [0, 2048) histogram of the top 11 bits of the order key, [2048, 2080) histogram of the low 5 bits inside the picked bin, 4 spare

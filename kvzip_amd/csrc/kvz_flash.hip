@@ -289,12 +289,19 @@ using namespace kvz;
 
 static inline size_t fl_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t kvz_flash_workspace_bytes(int Hkv, int G, int q_len, int D) {
-    if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0) return 0;
+static size_t flash16_workspace_bytes(int Hkv, int G, int q_len, int D) {
     const int R = q_len * G, ns = flash_splits(Hkv, R);
     if (ns <= 1) return 0;
     const size_t slots = (size_t)Hkv * R * ns;
     return fl_align256(slots * 2 * sizeof(float)) + fl_align256(slots * D * sizeof(float));
+}
+
+extern "C" size_t kvz_flash_workspace_bytes(int Hkv, int G, int q_len, int D) {
+    if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0) return 0;
+    const size_t w16 = flash16_workspace_bytes(Hkv, G, q_len, D);
+    if (!flash2_takes(Hkv, G, q_len, D)) return w16;
+    const size_t w32 = flash2_workspace_bytes(Hkv, G, q_len, D);  // (partials of its balanced partition)
+    return w32 > w16 ? w32 : w16;
 }
 
 extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k,
@@ -317,7 +324,7 @@ extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_str
                 "kvz_flash_fwd: output strides must be multiples of 4 elements");
     if (flash2_takes(Hkv, G, q_len, D) && (k_meta_host == nullptr || Hkv <= FL_MAXH))
         return flash2_fwd(q, q_stride_head, q_stride_group, q_stride_pos, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len,
-                          scale, causal, dtype, out, o_stride_head, o_stride_group, o_stride_pos, lse_out, (hipStream_t)stream_);
+                          scale, causal, dtype, out, o_stride_head, o_stride_group, o_stride_pos, lse_out, ws, ws_bytes, (hipStream_t)stream_);
     FlashArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.lse = lse_out;
     a.k_start = k_start; a.k_len = k_len; a.k_len_offset = k_len_offset;
@@ -331,7 +338,7 @@ extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_str
     a.Hkv = Hkv; a.G = G; a.q_len = q_len; a.causal = causal; a.scale = scale;
     // key splits only with a workspace that holds their partials (ws == NULL: every block walks all of its head's keys)
     a.ns = 1;
-    const size_t need = kvz_flash_workspace_bytes(Hkv, G, q_len, D);
+    const size_t need = flash16_workspace_bytes(Hkv, G, q_len, D);
     if (ws && need) {
         KVZ_REQUIRE(aligned16(ws), KVZ_EINVAL, "kvz_flash_fwd: workspace must be 16-byte aligned");
         KVZ_REQUIRE(ws_bytes >= need, KVZ_EWORKSPACE, "kvz_flash_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -365,6 +372,6 @@ extern "C" int kvz_flash_fwd_window(const void* q, int64_t q_stride_head, int64_
                     k_meta_host[Hkv + h], q_len);
     KVZ_REQUIRE(win_stats_head_stride >= (int64_t)G * q_len, KVZ_EINVAL, "kvz_flash_fwd_window: statistics stride too small");
     return flash2_fwd(q, q_stride_head, q_stride_group, q_stride_pos, k, v, nullptr, nullptr, 0, k_meta_host, Hkv, G, q_len, scale, 1,
-                      dtype, out, o_stride_head, o_stride_group, o_stride_pos, nullptr, (hipStream_t)stream_, win_sink, win_start, win_end,
+                      dtype, out, o_stride_head, o_stride_group, o_stride_pos, nullptr, nullptr, 0, (hipStream_t)stream_, win_sink, win_start, win_end,
                       win_stats, win_stats_head_stride);
 }

@@ -38,26 +38,6 @@ namespace kvz {
 constexpr int SC_TILE = 128;     // streamed rows per LDS tile (32 KiB at D = 128)
 constexpr int PB_WAVES = 8;              // waves per block of pass B: one 8-wave block per CU (three 32-KiB row-tile buffers; 4 LDS-DMA pieces per wave and tile)
 constexpr int PB_OCC = PB_WAVES / 4;     // waves per SIMD the register budget is sized for
-// division of a non-negative int (< 2^31) by a launch-invariant divisor: q = mulhi(n, m) >> sh with m = ceil(2^(31+l) / d),
-// l = ceil(log2 d) (Granlund-Montgomery round-up method, exact for 31-bit numerators).  A 32-bit division costs ~20 instructions;
-// the item switch of pass A had nine of them, executed by all eight waves.
-struct FastDiv {
-    uint32_t d, m, sh;  // sh = l - 1; d == 1 is the identity (m = 0)
-    __host__ __device__ inline int div(int n) const { return m ? (int)(__umulhi_((uint32_t)n, m) >> sh) : n; }
-    __host__ __device__ inline int mod(int n) const { return n - div(n) * (int)d; }
-    __host__ __device__ static inline uint32_t __umulhi_(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-};
-static inline FastDiv make_fastdiv(int d) {
-    FastDiv f;
-    f.d = (uint32_t)d;
-    if (d <= 1) { f.m = 0; f.sh = 0; return f; }
-    int l = 0;
-    while ((1ll << l) < d) ++l;
-    f.m = (uint32_t)((((uint64_t)1 << (31 + l)) + (uint64_t)d - 1) / (uint64_t)d);
-    f.sh = (uint32_t)(l - 1);
-    return f;
-}
-
 struct ScoreArgs {
     const void* q;       // [Hkv*G, q_len, D]
     const void* k;       // [Hkv, klen, D]

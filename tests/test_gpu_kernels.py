@@ -798,24 +798,32 @@ def test_flash2_dense_vs_fp32_reference(shape, dtype):
     prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
     try:
         out, lse = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
-        again, _ = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+        again, lse_again = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
     finally:
         lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1 << 30)
     try:
         old, lse_old = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)   # the 16-row kernel
     finally:
         lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
-    assert torch.equal(out, again)
+    assert torch.equal(out, again) and torch.equal(lse, lse_again)
     # round 4: the XCD-aware block order (a head's row tiles on 8 / Hkv XCDs; Hkv = 1, 2, 4, 8: XCDs per head, 16: heads per XCD,
-    # 3: head-major fallback; partial groups when 8 / Hkv does not divide the row tiles) only permutes blocks: same bits as head-major
-    prev_x = lib.kvz_debug_set_tunable(b"flash2_xcd", 0)
-    prev_b = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
-    try:
-        plain, lse_plain = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
-    finally:
-        lib.kvz_debug_set_tunable(b"flash2_xcd", prev_x)
-        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev_b)
-    assert prev_x == 1 and torch.equal(out, plain) and torch.equal(lse, lse_plain)
+    # 3: head-major fallback; partial groups when 8 / Hkv does not divide the row tiles) only permutes blocks: with one block per
+    # (head, row tile) - the balanced partition switched off - the bits are those of the head-major grid
+    variants = {}
+    # (flash2_split: 0 = one block per unit, 1 = split the last round of blocks along the keys when it saves a tenth of the rounds,
+    # 2 = whenever the units do not fill the last round - what these small shapes need to get there at all)
+    for name, xcd, split in (("unit_xcd", 1, 0), ("unit_plain", 0, 0), ("split_xcd", 1, 2), ("split_plain", 0, 2)):
+        prev_x = lib.kvz_debug_set_tunable(b"flash2_xcd", xcd)
+        prev_s = lib.kvz_debug_set_tunable(b"flash2_split", split)
+        prev_b = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+        try:
+            variants[name] = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+        finally:
+            lib.kvz_debug_set_tunable(b"flash2_xcd", prev_x)
+            lib.kvz_debug_set_tunable(b"flash2_split", prev_s)
+            lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev_b)
+        assert prev_x == 1 and prev_s == 1
+    assert torch.equal(variants["unit_xcd"][0], variants["unit_plain"][0]) and torch.equal(variants["unit_xcd"][1], variants["unit_plain"][1])
     s = torch.einsum("hid,hjd->hij", qq[0].float(), key[0].float().repeat_interleave(G, 0)) / math.sqrt(D)
     i = torch.arange(q_len, device=DEV).view(1, q_len, 1)
     j = torch.arange(klen, device=DEV).view(1, 1, klen)
@@ -826,8 +834,43 @@ def test_flash2_dense_vs_fp32_reference(shape, dtype):
     print(f"\nflash2 {shape} {dtype}: max |err| {float(err.max()):.2e} (16-row kernel: {float((old[0].float() - want).abs().max()):.2e})")
     check_attn(f"flash2_dense_vs_fp32_reference/{shape}/{dtype}", out[0], want.to(dtype), tol, ulp_of=dtype)   # (the oracle's contract: fp32 result rounded once)
     assert (lse[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
+    # the split cuts a unit's keys at other places with another block order, and not at all without it: same contract for each
+    for name, (o_v, lse_v) in variants.items():
+        check_attn(f"flash2_dense_vs_fp32_reference/{name}/{shape}/{dtype}", o_v[0], want.to(dtype), tol, ulp_of=dtype)
+        assert (lse_v[0] - torch.logsumexp(s, -1)).abs().max() <= 1e-3
     from conftest import grid_step
     assert ((out.float() - old.float()).abs().cpu() <= 2 * torch.maximum(torch.full_like(want, tol), grid_step(want, dtype)).unsqueeze(0).cpu()).all()
+
+
+@pytest.mark.parametrize("split", [2, 0])
+def test_flash2_rows_without_keys_and_uneven_units(split):
+    """The split last round of the 32-row forward on a call whose units differ as much as they can: fewer keys than query positions,
+    so the first row tiles see NO key (they weigh one virtual key tile and must still write zeros and lse = -inf), the last ones a
+    growing causal prefix.  Same answer with and without the split."""
+    from kvzip_amd import ops
+    lib = ops._lib.load()
+    H, Hkv, q_len, klen, D = 8, 2, 900, 333, 128
+    G = H // Hkv
+    g = torch.Generator(device=DEV).manual_seed(99)
+    key = torch.randn(1, Hkv, klen, D, generator=g, device=DEV).half()
+    val = torch.randn(1, Hkv, klen, D, generator=g, device=DEV).half()
+    qq = torch.randn(1, q_len, H, D, generator=g, device=DEV).half().transpose(1, 2)
+    prev_s = lib.kvz_debug_set_tunable(b"flash2_split", split)
+    prev_b = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    try:
+        out, lse = ops.flash_fwd(qq, key, val, causal=True, return_lse=True)
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_split", prev_s)
+        lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev_b)
+    s_ = torch.einsum("hid,hjd->hij", qq[0].float(), key[0].float().repeat_interleave(G, 0)) / math.sqrt(D)
+    i = torch.arange(q_len, device=DEV).view(1, q_len, 1)
+    j = torch.arange(klen, device=DEV).view(1, 1, klen)
+    s_ = s_.masked_fill(j > i + (klen - q_len), float("-inf"))
+    blind = q_len - klen   # positions 0 .. blind-1 see nothing
+    want = torch.einsum("hij,hjd->ihd", torch.nan_to_num(torch.softmax(s_, -1), nan=0.0), val[0].float().repeat_interleave(G, 0))
+    assert (out[0, :blind] == 0).all() and torch.isinf(lse[0, :, :blind]).all() and (lse[0, :, :blind] < 0).all()
+    check_attn(f"flash2_rows_without_keys/split{split}", out[0], want.half(), 1e-3, ulp_of=torch.float16)
+    assert (lse[0, :, blind:] - torch.logsumexp(s_, -1)[:, blind:]).abs().max() <= 1e-3
 
 
 def test_flash_attn_varlen_func_call_compatibility():
