@@ -352,9 +352,10 @@ int kvz_add_i32(int32_t* p, int delta, kvz_stream_t stream);
  * k_start[h] .. +k_len[h]+k_len_offset (device arrays, or k_meta_host = {start[Hkv], len[Hkv]} by value, up to 64 heads; either
  * may be NULL if the other is given).  Causal mask aligned bottom-right: position i sees keys j <= i + len_h - q_len.
  * lse_out: NULL or float [Hkv, q_len*G] (row i*G+g): natural-log LSE of the scaled logits, -inf for rows that see no key.
- * ws: NULL, or kvz_flash_workspace_bytes(...) bytes (no initialisation needed).  With few query rows (fewer than 256 blocks of
- * 128 rows over all heads) the keys of a head are split over up to 64 blocks whose partial results a second launch merges; that
- * needs the workspace.  Without one every block walks all keys of its head (correct, slower for few rows). */
+ * ws: NULL, or kvz_flash_workspace_bytes(...) bytes (no initialisation needed).  The keys of a head are split over several blocks
+ * whose partial results a second launch merges whenever whole (head, row tile) blocks would leave CUs idle - few query rows, or a
+ * number of row tiles that does not fill the last round of blocks; that needs the workspace (up to 68 MB at head_dim 128).
+ * Without one every block walks all keys of its head (correct, slower in those cases). */
 size_t kvz_flash_workspace_bytes(int Hkv, int G, int q_len, int D);
 int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos,
                   const void* k, const void* v,

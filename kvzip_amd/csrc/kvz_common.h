@@ -76,7 +76,7 @@ int tunable(Tunable t);
 float score_exact_reciprocal(int D, int dtype);
 
 // the 32-row dense forward (kvz_flash2.hip), reached through kvz_flash_fwd
-bool flash2_takes(int Hkv, int G, int q_len, int D);
+bool flash2_takes(int Hkv, int G, int q_len, int D, bool with_ws);
 size_t flash2_workspace_bytes(int Hkv, int G, int q_len, int D);
 int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int64_t q_stride_pos, const void* k, const void* v,
                const int32_t* k_start, const int32_t* k_len, int k_len_offset, const int32_t* k_meta_host, int Hkv, int G, int q_len,

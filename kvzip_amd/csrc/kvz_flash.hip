@@ -299,7 +299,7 @@ static size_t flash16_workspace_bytes(int Hkv, int G, int q_len, int D) {
 extern "C" size_t kvz_flash_workspace_bytes(int Hkv, int G, int q_len, int D) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || D <= 0) return 0;
     const size_t w16 = flash16_workspace_bytes(Hkv, G, q_len, D);
-    if (!flash2_takes(Hkv, G, q_len, D)) return w16;
+    if (!flash2_takes(Hkv, G, q_len, D, true)) return w16;
     const size_t w32 = flash2_workspace_bytes(Hkv, G, q_len, D);  // (partials of its balanced partition)
     return w32 > w16 ? w32 : w16;
 }
@@ -322,7 +322,8 @@ extern "C" int kvz_flash_fwd(const void* q, int64_t q_stride_head, int64_t q_str
                 "kvz_flash_fwd: query strides must be multiples of 8 elements");
     KVZ_REQUIRE(o_stride_head % 4 == 0 && o_stride_group % 4 == 0 && o_stride_pos % 4 == 0, KVZ_EINVAL,
                 "kvz_flash_fwd: output strides must be multiples of 4 elements");
-    if (flash2_takes(Hkv, G, q_len, D) && (k_meta_host == nullptr || Hkv <= FL_MAXH))
+    const size_t w32 = flash2_workspace_bytes(Hkv, G, q_len, D);
+    if (flash2_takes(Hkv, G, q_len, D, ws != nullptr && w32 != 0 && ws_bytes >= w32) && (k_meta_host == nullptr || Hkv <= FL_MAXH))
         return flash2_fwd(q, q_stride_head, q_stride_group, q_stride_pos, k, v, k_start, k_len, k_len_offset, k_meta_host, Hkv, G, q_len,
                           scale, causal, dtype, out, o_stride_head, o_stride_group, o_stride_pos, lse_out, ws, ws_bytes, (hipStream_t)stream_);
     FlashArgs a{};
@@ -360,7 +361,7 @@ extern "C" int kvz_flash_fwd_window(const void* q, int64_t q_stride_head, int64_
     KVZ_REQUIRE(q && k && v && out && k_meta_host && win_stats, KVZ_EINVAL, "kvz_flash_fwd_window: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= FL_MAXH && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_flash_fwd_window: bad shape");
     KVZ_REQUIRE(dtype == KVZ_F16 || dtype == KVZ_BF16, KVZ_EINVAL, "kvz_flash_fwd_window: bad dtype %d", dtype);
-    KVZ_REQUIRE(flash2_takes(Hkv, G, q_len, D), KVZ_EUNSUPPORTED,
+    KVZ_REQUIRE(flash2_takes(Hkv, G, q_len, D, false), KVZ_EUNSUPPORTED,
                 "kvz_flash_fwd_window: only the 32-row kernel emits the statistics (head_dim 128, >= %d row blocks)", tunable(TUNE_FLASH2_MIN_BLOCKS));
     KVZ_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
                     (reinterpret_cast<uintptr_t>(win_stats) & 7u) == 0, KVZ_EINVAL, "kvz_flash_fwd_window: alignment");

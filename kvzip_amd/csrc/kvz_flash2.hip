@@ -77,7 +77,7 @@ struct Flash2Args {
     float2* part_ml;                  // [2*split_blocks][F2_ROWS] (m in the exp2 domain, l)
     float4* part_o;                   // [2*split_blocks][D/4][F2_ROWS]: O^T, four consecutive d per element, rows contiguous
 };
-constexpr int F2_MAXPARTS = 8;
+constexpr int F2_MAXPARTS = 32;
 
 // ---- the split last round of an XCD group: nu units, nb blocks per round, rem = nu % nb units left for the last round ----
 // many helpers (nb - rem >= rem): each unit is cut into parts = 1 + helpers per unit equal parts (at most F2_MAXPARTS);
@@ -502,7 +502,8 @@ __global__ __launch_bounds__(F2_THREADS, 1) void flash2_fwd_kernel(Flash2Args a)
 }
 
 // Merge of the parts of the units of a split last round: one block per such unit (block (c, i) = i-th unit of group c's last round);
-// a unit with a single non-empty part has its result already.  Thread = (row, half of the head dim).
+// a unit with a single non-empty part has its result already.  blockIdx.y = one of the eight 32-row groups of the unit (a unit cut into
+// 32 parts is 4 MiB of partials: one block per unit left the merge of a few units slower than their forward); thread = (row, 8 of d).
 template <typename T>
 __global__ __launch_bounds__(F2_THREADS) void flash2_merge_kernel(Flash2Args a) {
     constexpr int D = 128, MAXSEG = F2_MAXPARTS;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(F2_THREADS) void flash2_merge_kernel(Flash2Args a) 
     if (nseg <= 1) return;  // one part walked the whole unit: stored by the forward
     const int R = a.q_len * a.G;
     const int rt = a.n_rt - 1 - xt;
-    const int row = threadIdx.x & (F2_ROWS - 1), dh = threadIdx.x / F2_ROWS;  // 512 threads: two halves of the head dim
+    const int row = (int)blockIdx.y * 32 + (threadIdx.x & 31), dh = threadIdx.x >> 5;  // 512 threads: 32 rows x 16 pairs of d-quads
     const int r = rt * F2_ROWS + row;
     if (r >= R) return;
     float M = -INFINITY;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(F2_THREADS) void flash2_merge_kernel(Flash2Args a) 
     const float inv = L > 0.f ? 1.f / L : 0.f;
     const int qi = a.dG.div(r), qg = r - qi * a.G;
     T* op = reinterpret_cast<T*>(a.out) + h * a.o_sh + qg * a.o_sg + qi * a.o_si;
-    for (int dq = dh * (D / 8); dq < (dh + 1) * (D / 8); ++dq) {
+    for (int dq = dh; dq < D / 4; dq += 16) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int sgm = 0; sgm < nseg; ++sgm) {
             const float4 p = a.part_o[((int64_t)slots[sgm] * (D / 4) + dq) * F2_ROWS + row];
@@ -551,11 +552,19 @@ __global__ __launch_bounds__(F2_THREADS) void flash2_merge_kernel(Flash2Args a) 
     if (a.lse && dh == 0) a.lse[(int64_t)h * R + r] = (L > 0.f) ? (M + log2f(L)) * 0.69314718055994530942f : -INFINITY;
 }
 
-// Does the 32-row kernel take this call?  Head dim 128, and enough (head, 256-row tile) blocks to fill the chip without key splits.
-bool flash2_takes(int Hkv, int G, int q_len, int D) {
+// Does the 32-row kernel take this call?  Head dim 128, and enough (head, 256-row tile) units: without a workspace every unit is one
+// block that walks all of its head's keys, so the units have to fill the chip by themselves (below that the 16-row kernel with its
+// key splits does better); with the workspace of the split last round two units per XCD are enough - their keys are cut into up
+// to F2_MAXPARTS parts.  Measured (profiles/r4_flash_small_shapes.txt, fp16, 28 / 4 heads): 16 units against 8 k keys 65 us, the
+// 16-row kernel 63; against 133 k keys 317 and 558; 56 units 1 033 and 2 035.  (8 units: 89 and 54 at 8 k keys, 216 and 287 at 133 k.)
+constexpr int F2_MIN_UNITS_SPLIT = 16;
+bool flash2_takes(int Hkv, int G, int q_len, int D, bool with_ws) {
     if (D != 128 || Hkv <= 0 || G <= 0 || q_len <= 0) return false;
     const int64_t blocks = (int64_t)((q_len * (int64_t)G + F2_ROWS - 1) / F2_ROWS) * Hkv;
-    return blocks >= tunable(TUNE_FLASH2_MIN_BLOCKS);  // fewer blocks: the 16-row kernel with key splits fills the chip better
+    int need = tunable(TUNE_FLASH2_MIN_BLOCKS);
+    // (a knob raised above its default keeps the 32-row kernel out altogether: that is how the tests force the 16-row kernel)
+    if (with_ws && tunable(TUNE_FLASH2_SPLIT) != 0 && need > F2_MIN_UNITS_SPLIT && need <= 128) need = F2_MIN_UNITS_SPLIT;
+    return blocks >= need;
 }
 
 // ---- balanced partition: grid and workspace ----
@@ -651,7 +660,7 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
 #undef KVZ_F2_LAUNCH
     KVZ_CHECK_LAUNCH("flash2_fwd_kernel");
     if (a.split_blocks) {
-        const dim3 mgrid(a.split_blocks);  // (at most blocks-per-round - 1 units per group are split)
+        const dim3 mgrid(a.split_blocks, F2_ROWS / 32);  // (at most blocks-per-round - 1 units per group are split)
         if (dtype == KVZ_F16) hipLaunchKernelGGL((flash2_merge_kernel<_Float16>), mgrid, block, 0, stream, a);
         else hipLaunchKernelGGL((flash2_merge_kernel<__bf16>), mgrid, block, 0, stream, a);
         KVZ_CHECK_LAUNCH("flash2_merge_kernel");

@@ -60,6 +60,17 @@ def test_host_only_entry_points():
     assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000, 32) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4
     assert lib.kvz_varlen_attn_workspace_bytes(4, 7, 1, 128, 131104) > 0
     assert lib.kvz_score_workspace_bytes(0, 7, 1, 1, 0) == 0
+    # dense forward: from 16 (head, 256-row tile) units on the 32-row kernel takes the call when it gets the workspace of its split last
+    # round - two partial slots (256 rows x (128 + 2) floats) per block of a round; below that the 16-row kernel's key splits
+    slot = 256 * (128 + 2) * 4
+    assert lib.kvz_flash_workspace_bytes(4, 7, 2026, 128) >= 2 * 256 * slot          # 224 units
+    assert lib.kvz_flash_workspace_bytes(4, 7, 128, 128) >= 2 * 256 * slot           # 16 units
+    assert 0 < lib.kvz_flash_workspace_bytes(4, 7, 100, 128) < 2 * 256 * slot        # 12 units: key splits of the 16-row kernel
+    prev = lib.kvz_debug_set_tunable(b"flash2_split", 0)
+    try:
+        assert prev == 1 and lib.kvz_flash_workspace_bytes(4, 7, 2026, 128) == 0     # enough units by themselves, nothing to merge
+    finally:
+        lib.kvz_debug_set_tunable(b"flash2_split", prev)
     # asynchronous-scoring contexts are host objects (events): creating / destroying them needs no kernel
     assert lib.kvz_async_create(0) < 0 and b"slot" in lib.kvz_last_error()
     assert lib.kvz_async_wait(12345, -1, None) < 0 and lib.kvz_async_destroy(12345) == 0
