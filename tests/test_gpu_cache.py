@@ -420,11 +420,13 @@ def test_score_forward_fused_statistics(dtype):
         return kv.score[0].cpu(), outs
 
     prev = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
+    prev_s = lib.kvz_debug_set_tunable(b"flash2_split", 0)   # (the window kernel never splits a unit's keys: compare like with like)
     try:
         s_fused, o_fused = run(True)
         s_two, o_two = run(False)
     finally:
         lib.kvz_debug_set_tunable(b"flash2_min_blocks", prev)
+        lib.kvz_debug_set_tunable(b"flash2_split", prev_s)
     for a, b in zip(o_fused, o_two):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "the statistics must not change the attention output"
     check_score_parity(f"fused_forward/{dtype}", s_fused, want)
