@@ -27,6 +27,10 @@ shapes = ((torch.float16, 28, 4, 2026, 133000), (torch.float16, 28, 4, 16000, 16
           (torch.float16, 40, 8, 2026, 133000), (torch.float16, 40, 8, 2026, 35000), (torch.float16, 24, 8, 2026, 35000))
 prev_b = lib.kvz_debug_set_tunable(b"flash2_min_blocks", 1)
 tag = os.path.basename(os.environ.get("KVZIP_HIP_LIB", "default"))
+for kv in filter(None, os.environ.get("KVZ_TUNE", "").split(",")):   # e.g. KVZ_TUNE=flash_rows64=1,flash2_split=2
+    k_, v_ = kv.split("=")
+    lib.kvz_debug_set_tunable(k_.encode(), int(v_))
+    tag += " " + kv
 if "F2_SPLIT" in os.environ:   # (libraries that know the knob: 0 = one block per unit)
     lib.kvz_debug_set_tunable(b"flash2_split", int(os.environ["F2_SPLIT"]))
     tag += " split=" + os.environ["F2_SPLIT"]
