@@ -937,7 +937,7 @@ def test_round_chain_exhaustive(dtype, D):
     x = bits.view(dtype)
     want = (x / math.sqrt(D))
     finite = torch.isfinite(x.float())
-    for force_div in (0, 1):
+    for force_div in (0, 1, 2):   # 2: the reciprocal through the kernels' own four-logit chain (fp16: the assembly block of quad_args)
         out = torch.empty(65536, dtype=torch.int16, device=DEV)
         rcp = C.c_float(0)
         rc = lib.kvz_debug_round_chain(bits.to(DEV).data_ptr(), 65536, D, 0 if dtype == torch.float16 else 1, force_div,
@@ -950,7 +950,7 @@ def test_round_chain_exhaustive(dtype, D):
         bad = torch.nonzero(~same).view(-1)[:8]
         assert same.all(), (dtype, D, force_div, int((~same).sum()), bad.tolist(), x[bad].tolist(),
                             got[bad].tolist(), want[bad].tolist())
-        if not force_div:
+        if force_div != 1:
             assert rcp.value != 0.0, "no exact reciprocal found: kernels would fall back to the slow division"
 
 
