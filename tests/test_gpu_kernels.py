@@ -672,9 +672,10 @@ def test_varlen_attn_ragged_items_and_workspace_reuse(dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("q_len", [64, 257])
 def test_varlen_attn_many_query_rows_ragged_on_the_32_row_kernel(q_len, dtype):
-    """The same ragged first-generation-step call forced onto the 32-row kernel (kvz_flash2.hip; it takes such calls by itself once
-    there are >= 128 row blocks, i.e. for long queries): head segments of 4 k / 33 / 1.5 k / 0 context keys + the query's own,
-    by-value and device-array metadata."""
+    """The same ragged first-generation-step call forced onto the 32-row kernel (kvz_flash2.hip; it takes such calls by itself from
+    16 (head, 256-row) units on, i.e. for queries of > 100 tokens) - with the workspace, so the keys of every unit are cut into parts
+    (heads of 4 k / 33 / 1.5 k / 0 context keys + the query's own: parts of very different lengths, empty ones included) and merged
+    by the second launch; by-value and device-array metadata."""
     from kvzip_amd import ops
     lib = ops._lib.load()
     Hkv, G, D = 4, 7, 128
