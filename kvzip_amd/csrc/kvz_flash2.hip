@@ -22,12 +22,12 @@
 //     group beyond its last full round of CUs/8 blocks are cut into key ranges so that all blocks of that round get the same
 //     number of key tiles: few helpers (28 units, 4 free CUs) -> every unit gives its last 1/8 of the keys to a tail block, the tail
 //     blocks queue behind the first parts and each free CU works through seven of them; many helpers (8 units, 24 free CUs) ->
-//     every unit is cut into four equal parts.  The blocks that
-//     own the FIRST part of their units still walk the same keys at the same time, so the L2 of an XCD keeps serving a key tile
-//     to all of them (a partition into arbitrary equal ranges was measured first: every block then streams its own keys from
-//     HBM and the kernel is 8-39 % slower than without any split).  A part stores an unnormalised partial (m, l, O^T in fp32)
-//     and a second launch merges the parts of a unit.
-// The 16-row kernel stays for what this one does not take: head dim 64, key splits for short row counts (kvz_flash.hip).
+//     every unit is cut into four equal parts (up to 32: a call with 16 units fills the chip that way, which is why such calls
+//     come here instead of going to the 16-row kernel).  The blocks that own the FIRST part of their units still walk the same
+//     keys at the same time, so the L2 of an XCD keeps serving a key tile to all of them (a partition into arbitrary equal ranges
+//     was measured first: every block then streams its own keys from HBM and the kernel is 8-39 % slower than without any split).
+//     A part stores an unnormalised partial (m, l, O^T in fp32) and a second launch merges the parts of a unit.
+// The 16-row kernel stays for what this one does not take: head dim 64, fewer than 16 units, calls without a workspace (kvz_flash.hip).
 #include "kvz_mfma_lds.h"
 
 #include <math.h>
