@@ -236,23 +236,35 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
             : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
     } else if constexpr (std::is_same<T, __bf16>::value && FAST) {
-        // bf16: there is no mixed-precision fma that reads a bf16 half, so every value goes f32 -> bf16 -> f32 twice.  Written on
-        // pairs: v_cvt_pk_bf16_f32 rounds two values per instruction, the way back is a shift / a mask, and the two fp32
-        // multiplications (by rcp, then by log2e with the addend) are packed v_pk_mul_f32 / v_pk_fma_f32: 16 instead of the 24
-        // instructions per four logits that the element-wise form compiles to.
-        typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-        auto round2 = [](f2v v) __attribute__((always_inline)) -> uint32_t {
-            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2v));
-        };
-        auto widen2 = [](uint32_t p) __attribute__((always_inline)) -> f2v {
-            return f2v{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
-        };
-        const f2v r2 = {rcp, rcp}, l2 = {L2E, L2E}, n2 = {neg_ml2, neg_ml2};
-        const f2v p01 = widen2(round2(f2v{a0, a1})) * r2, p23 = widen2(round2(f2v{a2, a3})) * r2;
-        xa = round2(p01);
-        xb = round2(p23);
-        const f2v g01 = __builtin_elementwise_fma(widen2(xa), l2, n2), g23 = __builtin_elementwise_fma(widen2(xb), l2, n2);
-        arg[0] = g01[0]; arg[1] = g01[1]; arg[2] = g23[0]; arg[3] = g23[1];
+        // bf16: there is no mixed-precision fma that reads a bf16 half, so every value goes f32 -> bf16 -> f32 twice:
+        // v_cvt_pk_bf16_f32 rounds two values per instruction, the way back is a shift / a mask, the two fp32 multiplications (by
+        // rcp, then by log2e with the addend) are PLAIN v_mul_f32 / v_fma_f32.  Round 2 had them packed (v_pk_mul_f32 /
+        // v_pk_fma_f32 on pairs, 16 instead of these 20 instructions per four logits): bit-identical, but packed fp32 arithmetic
+        // issues slower than two plain instructions on this part - the plain form takes 2 us off pass B (45.1 -> 43.1 us) and
+        // +1.2 % in the bf16 scoring loop (round 4, same box, three interleaved rounds).  Assembly, because the compiler packs
+        // adjacent fp32 operations again.
+        asm("v_cvt_pk_bf16_f32 %[xa], %[a0], %[a1]\n\t"
+            "v_cvt_pk_bf16_f32 %[xb], %[a2], %[a3]\n\t"
+            "v_lshlrev_b32 %[g0], 16, %[xa]\n\t"
+            "v_and_b32 %[g1], 0xffff0000, %[xa]\n\t"
+            "v_lshlrev_b32 %[g2], 16, %[xb]\n\t"
+            "v_and_b32 %[g3], 0xffff0000, %[xb]\n\t"
+            "v_mul_f32 %[g0], %[r], %[g0]\n\t"
+            "v_mul_f32 %[g1], %[r], %[g1]\n\t"
+            "v_mul_f32 %[g2], %[r], %[g2]\n\t"
+            "v_mul_f32 %[g3], %[r], %[g3]\n\t"
+            "v_cvt_pk_bf16_f32 %[xa], %[g0], %[g1]\n\t"
+            "v_cvt_pk_bf16_f32 %[xb], %[g2], %[g3]\n\t"
+            "v_lshlrev_b32 %[g0], 16, %[xa]\n\t"
+            "v_and_b32 %[g1], 0xffff0000, %[xa]\n\t"
+            "v_lshlrev_b32 %[g2], 16, %[xb]\n\t"
+            "v_and_b32 %[g3], 0xffff0000, %[xb]\n\t"
+            "v_fma_f32 %[g0], %[g0], %[l2e], %[nm]\n\t"
+            "v_fma_f32 %[g1], %[g1], %[l2e], %[nm]\n\t"
+            "v_fma_f32 %[g2], %[g2], %[l2e], %[nm]\n\t"
+            "v_fma_f32 %[g3], %[g3], %[l2e], %[nm]"
+            : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(arg[0]), [g1] "=&v"(arg[1]), [g2] "=&v"(arg[2]), [g3] "=&v"(arg[3])
+            : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp), [l2e] "v"(L2E), [nm] "v"(neg_ml2));
     } else {
         const T x0 = round_chain_h<T, FAST>(a0, c, rcp), x1 = round_chain_h<T, FAST>(a1, c, rcp);
         const T x2 = round_chain_h<T, FAST>(a2, c, rcp), x3 = round_chain_h<T, FAST>(a3, c, rcp);
