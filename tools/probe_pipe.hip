@@ -4,6 +4,7 @@
 // Reports cycles (s_memtime) per slot for: MFMA only / fillers only / interleaved / burst-then-fillers, 1 and 2 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -33,8 +34,8 @@ __device__ __forceinline__ void fillB(const float (&arg)[4], float& p0, float& p
 }
 // MODE 0 MFMA only, 1 fillers only, 2 interleaved (one slot = MFMA + filler block), 3 burst (32 MFMA, then 32 filler blocks)
 // FILL: filler blocks per slot x 2 (2 = the real load: A on even, B on odd slots; 1 = half of it; 4 = double)
-template <int NACC, int MODE, int FILL>
-__global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, float rcp) {
+template <int NACC, int MODE, int FILL, int BAR = 0>
+__global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, float rcp, unsigned seed) {
     h8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
     f16v acc[4];
@@ -44,7 +45,15 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
     const float l2e = 1.4426950408889634f, nm = -3.f;
     __shared__ __attribute__((aligned(16))) char lds[65536];
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    for (int o = threadIdx.x * 16; o < 65536; o += blockDim.x * 16) *(u4*)(lds + o) = u4{0x3c003c00u, 0x3c003c00u, 0x38003800u, 0x34003400u};
+    for (int o = threadIdx.x * 16; o < 65536; o += blockDim.x * 16) {
+        u4 w = u4{0x3c003c00u, 0x3c003c00u, 0x38003800u, 0x34003400u};
+        if (seed) {   // random fp16 values of magnitude 0.5 .. 2 with random signs and mantissas: realistic toggling on the LDS, MFMA and VALU paths
+            unsigned x = seed ^ (o * 2654435761u) ^ (blockIdx.x * 40503u);
+            for (int j = 0; j < 4; ++j) { x = x * 1664525u + 1013904223u; unsigned r = x >> 8; w[j] = (r & 0x83ff83ffu) | 0x38003800u | ((r >> 3) & 0x04000400u); }
+        }
+        *(u4*)(lds + o) = w;
+    }
+    if (seed) { unsigned x = seed ^ (threadIdx.x * 747796405u); for (int i = 0; i < 8; ++i) { x = x * 1664525u + 1013904223u; b[i] = (_Float16)(((int)((x >> 9) & 1023) - 512) * (1.0f / 512.f)); a[i] = (_Float16)(((int)((x >> 19) & 1023) - 512) * (1.0f / 512.f)); } }
     __syncthreads();
     u4 fr[2][8];
     const int fo = (threadIdx.x & 63) * 16;
@@ -91,6 +100,8 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (BAR == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (BAR == 2 && (threadIdx.x >> 8) == (it & 1)) { for (int z = 0; z < 30; ++z) asm volatile("s_nop 7"); }   // one half of the block falls behind, alternating
         } else if (MODE >= 4) {
             // the kernel's real shape: steps of 8 slots; the chain of a step accumulates into one set while the fillers read the
             // 16 values of the OTHER set (produced by the previous step's chain).  MODE 5: the values are first copied out of the
@@ -127,17 +138,20 @@ __global__ __launch_bounds__(512) void kp(float* out, unsigned long long* cyc, f
     out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
-template <int NACC, int MODE, int FILL> void run(const char* what, float* d, unsigned long long* c, int threads) {
+static unsigned g_seed = 0;
+template <int NACC, int MODE, int FILL, int BAR = 0> void run(const char* what, float* d, unsigned long long* c, int threads) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    kp<NACC, MODE, FILL><<<256, threads>>>(d, c, 0.0883883461f);
-    hipEventRecord(e0); kp<NACC, MODE, FILL><<<256, threads>>>(d, c, 0.0883883461f); hipEventRecord(e1); hipEventSynchronize(e1);
+    kp<NACC, MODE, FILL, BAR><<<256, threads>>>(d, c, 0.0883883461f, g_seed);
+    hipEventRecord(e0); kp<NACC, MODE, FILL, BAR><<<256, threads>>>(d, c, 0.0883883461f, g_seed); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
     const double slots = (double)ITERS * 32;
     printf("%-34s nacc %d  waves/SIMD %d : %7.1f ns/slot/wave  %6.1f memtime-ticks/slot  (SIMD: %.1f ns per slot-of-any-wave)\n", what, NACC, threads / 256,
            ms * 1e6 / slots, (double)cy / slots, ms * 1e6 / slots / (threads / 256));
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_seed = (unsigned)atoi(argv[1]);
+    printf("operand data: %s\n", g_seed ? "random" : "constant");
     float* d; hipMalloc(&d, 256 * 512 * 4);
     unsigned long long* c; hipMalloc(&c, 8);
     for (int threads : {256, 512}) {
@@ -159,6 +173,8 @@ int main() {
         run<2, 5, 2>("pipelined, other acc copied first", d, c, threads);
         run<2, 8, 2>("pipelined, A operands in 2 reg sets", d, c, threads);
         run<2, 7, 2>("pipelined, + 8 ds_read_b128 / step", d, c, threads);
+        run<2, 7, 2, 1>("  the same + s_barrier / 4 steps", d, c, threads);
+        run<2, 8, 2, 1>("  2 reg sets + s_barrier / 4 steps", d, c, threads);
     }
     printf("%s\n", hipGetErrorString(hipDeviceSynchronize()));
 }
