@@ -241,35 +241,42 @@ __global__ __launch_bounds__(AT_THREADS) void varlen_attn_split2_kernel(
     // ---- merge the 8 waves of the block through LDS (each wave writes only its own region) ----------
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    float* wo = reinterpret_cast<float*>(wl);            // [16 q][D]
-    float* wm = wo + AT_RT * D;                          // [16] m, [16] l
+    // Rows of D + 4 floats: with a stride of D floats (512 B) the 16 lanes of a quad - 16 query rows, the same output columns -
+    // all hit one LDS bank (round 5: 16-way conflict on every store, ~1 us per block, found by ablation: profiles/r5_decode_ablation.txt);
+    // the padded row puts the 16-byte stores of 8 consecutive query rows on 8 different bank groups.  Only valid query rows are
+    // written and merged (decode: G of the 16).
+    constexpr int WSTR = D + 4;                          // floats per staged row
+    static_assert((AT_RT * WSTR + 2 * AT_RT) * 4 <= C::WAVE_LDS, "the wave's V tile holds its merge staging");
+    float* wo = reinterpret_cast<float*>(wl);            // [16 q][D + 4]
+    float* wm = wo + AT_RT * WSTR;                       // [16] m, [16] l
+    const int rows_valid = min(AT_RT, R - rt * AT_RT);
+    if (l15 < rows_valid) {
 #pragma unroll
-    for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wo[l15 * D + db * 16 + quad * 4 + r] = o[db][r];
-    if (quad == 0) { wm[l15] = m_run; wm[16 + l15] = l_run; }
+        for (int db = 0; db < C::DB; ++db) *reinterpret_cast<f4*>(wo + l15 * WSTR + db * 16 + quad * 4) = o[db];
+        if (quad == 0) { wm[l15] = m_run; wm[16 + l15] = l_run; }
+    }
     __syncthreads();
 
-    const int rows_valid = min(AT_RT, R - rt * AT_RT);
     const int64_t pbase = ((int64_t)(first_item + split) * n_rtiles + rt) * AT_RT;  // partial slot of this item
-    for (int e = threadIdx.x; e < rows_valid * (D / 2); e += AT_THREADS) {
-        const int qq = e / (D / 2), d = (e % (D / 2)) * 2;
+    for (int e = threadIdx.x; e < rows_valid * (D / 4); e += AT_THREADS) {
+        const int qq = e / (D / 4), d = (e % (D / 4)) * 4;
         float mw[AT_WAVES], M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < AT_WAVES; ++w) {
-            mw[w] = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[AT_RT * D + qq];
+            mw[w] = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[AT_RT * WSTR + qq];
             M = fmaxf(M, mw[w]);
         }
-        float a0 = 0.f, a1 = 0.f, lsum = 0.f;
+        f4 acc4 = f4{0.f, 0.f, 0.f, 0.f};
+        float lsum = 0.f;
 #pragma unroll
         for (int w = 0; w < AT_WAVES; ++w) {
             const float* pw = reinterpret_cast<const float*>(lds + w * C::WAVE_LDS);
             const float wgt = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - M);
-            a0 += wgt * pw[qq * D + d];
-            a1 += wgt * pw[qq * D + d + 1];
-            lsum += wgt * pw[AT_RT * D + 16 + qq];
+            const f4 ov = *reinterpret_cast<const f4*>(pw + qq * WSTR + d);
+            acc4[0] += wgt * ov[0]; acc4[1] += wgt * ov[1]; acc4[2] += wgt * ov[2]; acc4[3] += wgt * ov[3];
+            lsum += wgt * pw[AT_RT * WSTR + 16 + qq];
         }
-        *reinterpret_cast<float2*>(part_o + (pbase + qq) * D + d) = make_float2(a0, a1);
+        *reinterpret_cast<f4*>(part_o + (pbase + qq) * D + d) = acc4;
         if (d == 0) *reinterpret_cast<float2*>(part_ml + (pbase + qq) * 2) = make_float2(M, lsum);
     }
 }
