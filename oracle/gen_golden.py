@@ -407,6 +407,62 @@ def gen_e2e_d128_512k(KVScore):
     np.savez_compressed(os.path.join(OUT, "g10_e2e_d128_512k.npz"), **out)
 
 
+E2E_RATIOS = (0.1, 0.3, 0.6, 0.9)
+
+
+def gen_e2e_ratios(KVScore):
+    """G12 (round 5): the REFERENCE's _threshold (attention/score.py:88-102) at ratios 0.1 / 0.3 / 0.6 / 0.9 on the reference's own
+    G10 scores (8 layers x 8 chunks, 512 000 scores per dtype; the scores are read back from g10_e2e_d128_512k.npz, where the
+    reference's _get_score put them).  Stored per dtype and ratio: threshold, packed mask, kept count per (layer, head)."""
+    g10 = np.load(os.path.join(OUT, "g10_e2e_d128_512k.npz"))
+    L, H, Hkv, D, sink, N, chunk = [int(x) for x in g10["geom"]]
+    sc = KVScore()
+    out = {"ratios": np.array(E2E_RATIOS, dtype=np.float64)}
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        score = torch.from_numpy(g10[f"{tag}/score"].astype(np.int16)).view(dt).reshape(L, 1, Hkv, N)
+        lst = [score[i] for i in range(L)]                # the list-of-layers form prune() passes after scoring
+        for r in E2E_RATIOS:
+            valid, thres = sc._threshold(lst, r)
+            if r == 0.3:                                  # must reproduce what G10 itself stored
+                assert thres == float(g10[f"{tag}/thres"][0]) and np.array_equal(np.packbits(valid.numpy().reshape(-1)), g10[f"{tag}/valid"])
+            out[f"{tag}/thres/{r!r}"] = np.array([thres], dtype=np.float64)
+            out[f"{tag}/valid/{r!r}"] = np.packbits(valid.numpy().reshape(-1))
+            out[f"{tag}/kept/{r!r}"] = valid.sum(-1).reshape(L, Hkv).numpy().astype(np.int32)
+            print("g12", tag, r, "thres", thres, "kept", int(valid.sum()), "of", valid.numel(), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g12_e2e_ratios.npz"), **out)
+
+
+def gen_uniform_ties(KVScore):
+    """G13 (round 5): _threshold_uniform (attention/score.py:104-120) on rows WITH ties - bf16 softmax-max-like scores (a few hundred
+    distinct values per row) and fp16 rows quantised to 64 levels.  torch.topk's choice among equal values is
+    implementation-defined, so the fixture pins the CONTRACT the build documents for pair-uniform, not positions among equals:
+    exactly k = int(N * ratio) kept per (layer, head), the kept multiset, and the mask wherever a score differs from the row's
+    boundary value (the k-th largest)."""
+    sc = KVScore()
+    g = torch.Generator().manual_seed(13)
+    out = {}
+    L, Hkv, N = 3, 4, 1000
+    base = torch.rand(L, 1, Hkv, N, generator=g) ** 4
+    cases = {"bf16": base.to(torch.bfloat16), "f16q": (torch.round(base * 64) / 64).to(torch.float16)}
+    cases["f16q"][0, 0, 0, :] = 0.25                      # a row of ONE value: every position ties
+    ratios = (0.1, 0.3, 0.6, 0.95)
+    out["ratios"] = np.array(ratios, dtype=np.float64)
+    for tag, score in cases.items():
+        out[f"{tag}/score"] = bits(score)
+        for r in ratios:
+            valid, thres = sc._threshold_uniform([score[i] for i in range(L)], r)
+            assert thres == 0
+            k = int(N * r)
+            assert bool((valid.sum(-1) == k).all())
+            # boundary value of every row = its k-th largest; ties exist there in (almost) every row of these inputs
+            kth = torch.sort(score.float(), dim=-1, descending=True).values[..., k - 1:k]
+            n_tied = int(((score.float() == kth).sum(-1) > 1).sum())
+            out[f"{tag}/valid/{r!r}"] = np.packbits(valid.numpy().reshape(-1))
+            out[f"{tag}/kth/{r!r}"] = bits(kth.to(score.dtype))
+            print("g13", tag, r, "k", k, "rows with a tie at the boundary:", n_tied, "of", L * Hkv, flush=True)
+    np.savez_compressed(os.path.join(OUT, "g13_uniform_ties.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -422,6 +478,10 @@ def main():
     if "--only-e2e-llama" in sys.argv:
         gen_e2e_llama(KVScore)
         return
+    if "--only-round5" in sys.argv:
+        gen_e2e_ratios(KVScore)
+        gen_uniform_ties(KVScore)
+        return
     gen_score(KVScore)
     gen_threshold(KVScore)
     gen_head_scores(KVScore)
@@ -431,6 +491,8 @@ def main():
     gen_e2e_d128(KVScore)
     gen_e2e_d128_512k(KVScore)
     gen_e2e_llama(KVScore)
+    gen_e2e_ratios(KVScore)
+    gen_uniform_ties(KVScore)
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print(f"wrote {OUT}: {total / 1e6:.2f} MB")
 

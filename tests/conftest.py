@@ -48,26 +48,25 @@ def ulp_diff(a, b):
     return (key(a) - key(b)).abs()
 
 
-# ---- score parity bookkeeping -------------------------------------------------------------------------------------------
-# The scoring kernels follow the reference's rounding chain; what differs from the CPU oracle is the accumulation order of the
-# fp32 dot products (and exp / log implementations), so a small fraction of the 16-bit scores lands one or a few steps of the
-# 16-bit grid away.  Every GPU test that compares scores goes through check_score_parity: it prints the measured distribution,
-# records it (KVZ_RECORD_PARITY=1 -> gpurun_out/score_parity_measured.json) and bounds it at TWICE the values measured on MI355X
-# and committed in tests/golden/score_parity_measured.json (+2 elements of slack for the tiny cases); a case without a record
-# falls back to the structural bound (>= 97 % identical, >= 99.5 % within one step, worst 16 = one ulp of the winning logit).
-_MEASURED = None
+# ---- score parity: fixed structural bounds --------------------------------------------------------------------------------
+# The scoring kernels follow the reference's rounding chain (attention/score.py:57-61); what differs from the CPU reference is the
+# accumulation order of the fp32 dot products inside the MFMA (and exp / log implementations), so a small fraction of the 16-bit
+# scores lands a few steps of the 16-bit grid away.  Round 5: the bounds are FIXED per dtype - they no longer follow the last
+# measurement (rounds 2-4 asserted "no worse than 2x what was recorded", which a regression could ratchet):
+#   fp16   >= 99.8 %  bit-identical, >= 99.95 % within one step, worst <= 8 steps
+#   bf16   >= 99.95 % bit-identical, >= 99.99 % within one step, worst <= 8 steps
+# (+ a few elements of slack so that cases of a few hundred scores are not decided by one element).  Why 8 is structural: when the
+# accumulation order flips the 16-bit rounding of the WINNING logit x (|x| < 8 for the inputs of every test: one step of x is at
+# most 2^-8 in fp16, 2^-5 in bf16) the score exp(x - m - log l) moves by that relative amount = 8 steps of its own grid.  Every
+# comparison is still printed and, with KVZ_RECORD_PARITY=1, recorded (gpurun_out/score_parity_measured.json; the records of
+# round 4 stay in tests/golden/score_parity_measured.json as documentation: worst case there 0.64 % / 0.022 % / 8).
+SCORE_BOUNDS = {  # dtype: (not identical <= a * n + b, beyond one step <= c * n + d, worst)
+    torch.float16: (0.002, 8, 0.0005, 2, 8),
+    torch.bfloat16: (0.0005, 4, 0.0001, 2, 8),
+}
 
 
-def _measured():
-    global _MEASURED
-    if _MEASURED is None:
-        import json
-        path = os.path.join(GOLDEN, "score_parity_measured.json")
-        _MEASURED = json.load(open(path)) if os.path.exists(path) else {}
-    return _MEASURED
-
-
-def check_score_parity(case: str, got, want):
+def check_score_parity(case: str, got, want, worst_allowed=None):
     import json
     d = ulp_diff(got, want)
     n = d.numel()
@@ -79,13 +78,33 @@ def check_score_parity(case: str, got, want):
         rec = json.load(open(path)) if os.path.exists(path) else {}
         rec[case] = {"n": n, "not_identical": n_diff, "beyond_one_step": n_far, "worst": worst}
         json.dump(rec, open(path, "w"), indent=0, sort_keys=True)
-    m = _measured().get(case)
-    if m is None:
-        assert n_diff <= 0.03 * n + 2 and n_far <= 0.005 * n + 1 and worst <= 16, (case, n, n_diff, n_far, worst)
-    else:
-        assert n_diff <= 2 * m["not_identical"] + 2 and n_far <= 2 * m["beyond_one_step"] + 1 and worst <= max(2 * m["worst"], 2), \
-            (case, n, n_diff, n_far, worst, m)
+    a, b, c, e, w = SCORE_BOUNDS[want.dtype]
+    w = w if worst_allowed is None else worst_allowed
+    assert n_diff <= a * n + b and n_far <= c * n + e and worst <= w, (case, str(want.dtype), n, n_diff, n_far, worst)
     return 1 - n_diff / max(n, 1), 1 - n_far / max(n, 1), worst
+
+
+def check_uniform_contract(case: str, score, valid, ref_valid, k: int):
+    """pair-uniform selection (attention/score.py:104-120) on rows WITH ties.  torch.topk's choice among equal values is
+    implementation-defined, so what the build promises - and what this asserts against the REFERENCE's mask - is:
+    exactly k kept per (layer, head) row, the same multiset of kept values, and the identical mask wherever a score differs from the
+    row's boundary value (the k-th largest): only WHICH of the entries equal to the boundary value are kept may differ."""
+    N = score.shape[-1]
+    s = score.detach().cpu().float().reshape(-1, N)
+    v = valid.detach().cpu().bool().reshape(-1, N)
+    r = ref_valid.detach().cpu().bool().reshape(-1, N)
+    assert bool((v.sum(-1) == k).all()) and bool((r.sum(-1) == k).all()), (case, "kept per row != k")
+    if k == 0:
+        return 0
+    kth = torch.sort(s, dim=-1, descending=True).values[:, k - 1:k]
+    off = s != kth
+    assert torch.equal(v & off, r & off), (case, "mask differs away from the boundary value")
+    assert torch.equal(torch.sort(torch.where(v, s, torch.full_like(s, -1e30)), dim=-1).values,
+                       torch.sort(torch.where(r, s, torch.full_like(s, -1e30)), dim=-1).values), (case, "kept multiset differs")
+    moved = int((v != r).sum())
+    print(f"\nUNIFORM {case}: k = {k}, rows {s.shape[0]}, rows with a tie at the boundary {int(((s == kth).sum(-1) > 1).sum())}, "
+          f"entries placed differently among equals {moved}")
+    return moved
 
 
 def grid_step(x: torch.Tensor, dtype) -> torch.Tensor:

@@ -67,7 +67,8 @@ def _bench_entry(argv):
     import time
     import bench
     out_dir, L, Hkv = argv[0], int(argv[1]), int(argv[2])
-    ranks = bench.Ranks(2, "gloo")
+    world = int(argv[3]) if len(argv) > 3 else 2
+    ranks = bench.Ranks(world, "gloo")
     ranks.barrier()
     t0 = time.perf_counter()
     len_k = torch.full((L, Hkv), 1000 * (ranks.rank + 1), dtype=torch.int32)
@@ -95,6 +96,24 @@ def test_bench_self_spawn_and_rank_logic_world2_gloo(tmp_path, monkeypatch):
         assert d["rank"] == r == d["local_rank"] and d["world"] == 2
         assert d["thres"] == [0.25, 1.25] and d["len00"] == [1000, 2000] and d["n_kept"] == [6000, 12000]
     assert res[0]["elapsed"] == res[1]["elapsed"] >= res[1]["mine"] >= 0.5   # MAX over ranks, identical everywhere
+
+
+def test_bench_self_spawn_world8_gloo_record_order(tmp_path, monkeypatch):
+    """The shape of BASELINE config C4 (8 independent contexts, one per rank) on CPU: `bench.launch` spawns EIGHT ranks over gloo,
+    every rank contributes the record of its own context, and every rank must see all eight records in context order (shard order =
+    rank order at N = 8) and the same max-over-ranks time.  The 8-GPU run itself needs a node this pool does not hand out."""
+    import json
+    import bench
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(var, raising=False)
+    bench.launch([str(tmp_path), "4", "2", "8"], _bench_entry, 8)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(8)]
+    for r, d in enumerate(res):
+        assert d["rank"] == r == d["local_rank"] and d["world"] == 8
+        assert d["thres"] == [0.25 + i for i in range(8)]
+        assert d["len00"] == [1000 * (i + 1) for i in range(8)] and d["n_kept"] == [8 * 1000 * (i + 1) for i in range(8)]
+    assert len({d["elapsed"] for d in res}) == 1 and res[0]["elapsed"] >= res[1]["mine"] >= 0.5
+    assert [shard_contexts(8, r, 8) for r in range(8)] == [[i] for i in range(8)]
 
 
 def test_bench_ranks_rejects_wrong_world(monkeypatch):

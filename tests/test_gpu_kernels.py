@@ -232,6 +232,24 @@ def test_select_topk_rows_golden():
         assert (counts.cpu() == k).all()
 
 
+def test_select_topk_rows_contract_on_reference_rows_with_ties():
+    """G13 (round 5, reference-generated): pair-uniform selection on rows WITH ties through kvz_select_topk_rows against the masks of
+    the reference's _threshold_uniform (attention/score.py:104-120): exactly k per (layer, head), the same kept multiset, the
+    identical mask away from each row's boundary value (conftest.check_uniform_contract) - the documented contract on exactly the
+    inputs where torch.topk's order is implementation-defined."""
+    from conftest import check_uniform_contract
+    g = load_golden("g13_uniform_ties.npz")
+    for tag, bf in (("bf16", True), ("f16q", False)):
+        score = from_bits(g[f"{tag}/score"], bf)
+        N = score.shape[-1]
+        for r in g["ratios"].tolist():
+            k = int(N * r)
+            ref = torch.from_numpy(np.unpackbits(g[f"{tag}/valid/{r!r}"])[:score.numel()]).bool().view(score.shape)
+            valid, counts = ops().select_topk_rows(score.to(DEV), k)
+            assert (counts.cpu() == k).all()
+            check_uniform_contract(f"hip/{tag}/{r}", score, valid.cpu(), ref, k)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_select_topk_rows_ties_vs_oracle(dtype):
     g = torch.Generator().manual_seed(11)

@@ -258,6 +258,40 @@ def test_oracle_threshold_on_e2e_d128_512k_fixture():
         assert np.array_equal(valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32), g[f"{tag}/kept"])
 
 
+def test_oracle_threshold_on_e2e_ratios_fixture():
+    """G12 (round 5): the reference's _threshold at ratios 0.1 / 0.3 / 0.6 / 0.9 on its own 512 000 G10 scores per dtype: the oracle
+    reproduces every threshold, mask and per-(layer, head) kept count bit for bit."""
+    import e2e_inputs as E
+    g10, g12 = load_golden("g10_e2e_d128_512k.npz"), load_golden("g12_e2e_ratios.npz")
+    geom = E.GEOM_512K
+    assert g12["ratios"].tolist() == [0.1, 0.3, 0.6, 0.9]
+    for tag, bf in (("f16", False), ("bf16", True)):
+        want = from_bits(g10[f"{tag}/score"], bf)
+        for r in g12["ratios"].tolist():
+            valid, thres = orc.threshold([want[i] for i in range(geom["L"])], r)
+            assert thres == float(g12[f"{tag}/thres/{r!r}"][0]), (tag, r)
+            assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g12[f"{tag}/valid/{r!r}"]), (tag, r)
+            assert np.array_equal(valid.sum(-1).reshape(geom["L"], geom["Hkv"]).numpy().astype(np.int32), g12[f"{tag}/kept/{r!r}"])
+
+
+def test_oracle_threshold_uniform_contract_on_rows_with_ties():
+    """G13 (round 5): the reference's _threshold_uniform on rows WITH ties (bf16 scores, quantised fp16 scores, a row of one value).
+    torch.topk's order among equal values is implementation-defined; the oracle (lowest index first) meets the documented contract
+    against the REFERENCE's masks: k per row, same kept multiset, identical away from the boundary value."""
+    from conftest import check_uniform_contract
+    g = load_golden("g13_uniform_ties.npz")
+    for tag, bf in (("bf16", True), ("f16q", False)):
+        score = from_bits(g[f"{tag}/score"], bf)
+        L, N = score.shape[0], score.shape[-1]
+        for r in g["ratios"].tolist():
+            ref = torch.from_numpy(np.unpackbits(g[f"{tag}/valid/{r!r}"])[:score.numel()]).bool().view(score.shape)
+            valid, thres = orc.threshold_uniform([score[i] for i in range(L)], r)
+            assert thres == 0
+            check_uniform_contract(f"oracle/{tag}/{r}", score, valid, ref, int(N * r))
+            kth = from_bits(g[f"{tag}/kth/{r!r}"], bf).float()
+            assert torch.equal(torch.sort(score.float(), dim=-1, descending=True).values[..., int(N * r) - 1:int(N * r)], kth)
+
+
 def test_oracle_threshold_on_e2e_llama_fixture():
     """G11 (Llama-3.1-8B head geometry, reference-generated): threshold, mask and kept counts of the reference reproduced by the oracle
     on the reference's scores, and one (layer, chunk) get_score call reproduced bit for bit (G = 4 path of the restatement)."""
