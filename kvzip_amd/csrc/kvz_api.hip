@@ -97,12 +97,20 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 // flash2_xcd: 1 = XCD-aware block order of the 32-row dense forward (a head's row tiles on 8 / Hkv XCDs), 0 = head-major grid.
 // flash2_split: 1 = the last round of blocks of the 32-row dense forward is split along the keys when that saves a tenth of the rounds
 //   (parts merged by a second launch; needs the workspace), 2 = whenever the units do not fill the last round (tests), 0 = never.
-// sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (256 / 256:
-//   every block costs a histogram flush or a prologue, profiles/r4_select.txt).
+// sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (default 0 =
+//   one per CU, device_cus(): every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 256, 256, 1};
-static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {256}, {256}, {1}};   // (atomic: a probe may flip a knob while another thread launches)
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}};   // (atomic: a probe may flip a knob while another thread launches)
 int tunable(Tunable t) { return g_tune[t].load(std::memory_order_relaxed); }
+int device_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
+}
 }  // namespace kvz
 extern "C" int kvz_debug_set_tunable(const char* name, int value) {
     KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_set_tunable: null name");

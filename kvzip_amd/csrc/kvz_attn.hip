@@ -406,14 +406,15 @@ __global__ __launch_bounds__(CB_THREADS) void varlen_attn_combine2_kernel(const 
 
 __global__ void add_i32_kernel(int32_t* p, int delta) { *p += delta; }
 
-// work items a decode call is cut into.  Default (knob 0): 256 - Hkv, the most that can never exceed one block per CU (every head
+// work items a decode call is cut into.  Default (knob 0): CUs - Hkv (256 - Hkv on MI355X), the most that can never exceed one block per CU (every head
 // rounds its item count up, so a call has at most target + Hkv items; one item beyond 256 costs a second round of blocks: 25 -> 34 us
 // per layer, profiles/r4_decode_cold_probe.txt).  Round 2 had settled on 192 with a probe whose single 80-MB cache lived in the
 // infinity cache; streaming a whole model's caches from cold HBM, 252 items are 3 % faster than 192.
 static inline int attn_items(int Hkv) {
     const int t = tunable(TUNE_ATTN_ITEMS);
     if (t > 0) return t;
-    return Hkv < 192 ? 256 - Hkv : 64;
+    const int cus = device_cus();
+    return Hkv < cus * 3 / 4 ? cus - Hkv : cus / 4;
 }
 static inline size_t align256a(size_t x) { return (x + 255) & ~(size_t)255; }
 struct AttnWs { uint32_t* counters; float* part_ml; float* part_o; size_t bytes; };

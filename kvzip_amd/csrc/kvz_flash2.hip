@@ -569,14 +569,7 @@ bool flash2_takes(int Hkv, int G, int q_len, int D, bool with_ws) {
 
 // ---- balanced partition: grid and workspace ----
 // One block per CU (96 KiB of LDS), a multiple of 8 so that every XCD group has the same number of blocks.
-static int f2_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        return cus >= 8 ? cus / 8 * 8 : 256;
-    }();
-    return n;
-}
+static int f2_cus() { const int cus = device_cus(); return cus >= 8 ? cus / 8 * 8 : 256; }
 constexpr size_t F2_SLOT_BYTES = (size_t)F2_ROWS * sizeof(float2) + (size_t)F2_ROWS * 128 * sizeof(float);
 static inline size_t f2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // XCD-aware order of the units (see the kernel): mode, parameter, number of groups
@@ -589,10 +582,25 @@ static void f2_order(int Hkv, int& mode, int& par, int& groups) {
 }
 // Blocks of a round: one per CU.
 static int f2_split_blocks() { return f2_cus(); }
+// Does this call split its last round of blocks along the keys (and therefore touch the workspace)?  One predicate for the
+// workspace size and the launch (round 5, ADVICE: the size used to be 2 x CUs x 133 KiB = 68 MB for EVERY head-dim-128 call, which
+// ops.flash_fwd then allocated per layer although full-chip prefill shapes never split).
+static bool f2_will_split(int Hkv, int n_rt, int* groups_out, int* nu_max_out, int* nb_g_out) {
+    int xcd_mode, xcd_par, groups;
+    f2_order(Hkv, xcd_mode, xcd_par, groups);
+    const int nb_g = f2_split_blocks() / groups;
+    const int nu_max = xcd_mode == 1 ? (n_rt + xcd_par - 1) / xcd_par : (xcd_mode == 2 ? xcd_par * n_rt : n_rt * Hkv);
+    const int rounds = (nu_max + nb_g - 1) / nb_g;
+    if (groups_out) *groups_out = groups;
+    if (nu_max_out) *nu_max_out = nu_max;
+    if (nb_g_out) *nb_g_out = nb_g;
+    if (tunable(TUNE_FLASH2_SPLIT) == 0) return false;
+    return nu_max % nb_g != 0 && (tunable(TUNE_FLASH2_SPLIT) >= 2 || 10 * rounds * nb_g >= 11 * nu_max);
+}
 size_t flash2_workspace_bytes(int Hkv, int G, int q_len, int D) {
-    if (D != 128 || Hkv <= 0 || G <= 0 || q_len <= 0 || tunable(TUNE_FLASH2_SPLIT) == 0) return 0;
+    if (D != 128 || Hkv <= 0 || G <= 0 || q_len <= 0) return 0;
     const int n_rt = (int)(((int64_t)q_len * G + F2_ROWS - 1) / F2_ROWS);
-    (void)n_rt;
+    if (!f2_will_split(Hkv, n_rt, nullptr, nullptr, nullptr)) return 0;
     return f2_align256((size_t)2 * f2_split_blocks() * F2_SLOT_BYTES);
 }
 
@@ -634,10 +642,8 @@ int flash2_fwd(const void* q, int64_t q_stride_head, int64_t q_stride_group, int
     const size_t need = win_stats ? 0 : flash2_workspace_bytes(Hkv, G, q_len, 128);
     if (ws && need && ws_bytes >= need) {
         KVZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, KVZ_EINVAL, "kvz_flash_fwd: workspace must be 16-byte aligned");
-        const int nb_g = f2_split_blocks() / groups;
-        const int nu_max = a.xcd_mode == 1 ? (a.n_rt + a.xcd_par - 1) / a.xcd_par : (a.xcd_mode == 2 ? a.xcd_par * a.n_rt : a.n_rt * Hkv);
-        const int rounds = (nu_max + nb_g - 1) / nb_g;
-        if (nu_max % nb_g != 0 && (tunable(TUNE_FLASH2_SPLIT) >= 2 || 10 * rounds * nb_g >= 11 * nu_max)) {
+        int nb_g = 0, nu_max = 0;
+        if (f2_will_split(Hkv, a.n_rt, nullptr, &nu_max, &nb_g)) {   // (need != 0 says so already; the numbers are needed below)
             a.split_blocks = f2_split_blocks();
             a.part_ml = reinterpret_cast<float2*>(ws);
             a.part_o = reinterpret_cast<float4*>(reinterpret_cast<char*>(ws) + (size_t)2 * a.split_blocks * F2_ROWS * sizeof(float2));

@@ -1595,7 +1595,7 @@ extern "C" int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void*
     KVZ_REQUIRE(hipMemsetAsync(select_ws, 0, SEL_WS_WORDS * sizeof(uint32_t), stream) == hipSuccess, KVZ_ELAUNCH,
                 "kvz_score_finalize_log_hist: hipMemsetAsync failed");
     int blocks = (int)(((n + 7) / 8 + 1023) / 1024);
-    if (blocks > 256) blocks = 256;  // one 1024-thread block per CU: every block flushes its non-empty bins with global atomics (kvz_select.hip)
+    if (blocks > device_cus()) blocks = device_cus();  // one 1024-thread block per CU: every block flushes its non-empty bins with global atomics (kvz_select.hip)
     if (blocks < 1) blocks = 1;
     uint32_t* hist = reinterpret_cast<uint32_t*>(select_ws);
     ProfScope ps("score_finalize_log", stream);

@@ -24,6 +24,7 @@ constexpr int HIST_THREADS = 1024;      // histogram and mask passes: one big bl
                                         // 131 / 224 us with 256 / 512 / 1024 / 2048 / 4096 blocks of 256 threads (profiles/r4_select.txt)
 constexpr int SEL_UNROLL = 8;         // 16-byte loads a thread keeps in flight in the streaming passes
 constexpr size_t SELECT_WS_WORDS = SEL_WS_WORDS;
+constexpr uint32_t SEL_BIN_NONE = 0xFFFFFFFFu;   // find_bin_wave: the rank lies beyond the histogram's total
 
 typedef kvz_u32x4 u32x4;
 
@@ -72,6 +73,9 @@ __device__ static inline void find_bin_wave(const uint32_t* __restrict__ hist, u
     __shared__ uint64_t s_rank;
     if (threadIdx.x < 64) {
         const int t = threadIdx.x;
+        // idx >= the histogram's total (a workspace that does not belong to these scores, kvz_select_threshold_prehist): no lane
+        // finds the rank - the sentinel makes the threshold NaN (nothing kept, the host raises) instead of whatever LDS held
+        if (t == 0) { s_bin = SEL_BIN_NONE; s_rank = 0; }
         uint32_t loc[PER];
         uint64_t sum = 0;
 #pragma unroll
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(HIST_THREADS) void select_emit_kernel(
     find_bin_wave<LO_BINS>(hist_lo, rank, &lo, &rank2);
     const uint32_t tkey = (bin << 5) | lo;
     const uint32_t tbits = order_key16_inv(tkey);
-    const float thres = half_bits_to_float(tbits, dtype);
+    const bool lost = bin == SEL_BIN_NONE || lo == SEL_BIN_NONE;   // the histograms do not hold rank idx: they are not of these scores
+    const float thres = lost ? __builtin_nanf("") : half_bits_to_float(tbits, dtype);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *thres_dev = thres;
 
     const int64_t row = blockIdx.y;
@@ -457,8 +462,8 @@ static int select_threshold_impl(const void* scores, int64_t n, double ratio, in
 
     const int64_t nvec = (n + 7) >> 3;
     int blocks = (int)((nvec + HIST_THREADS - 1) / HIST_THREADS);
-    const int cap = tunable(TUNE_SEL_BLOCKS);
-    if (blocks > cap) blocks = cap;  // (256 = one 1024-thread block per CU: every block flushes its non-empty bins with global atomics)
+    const int cap = tunable(TUNE_SEL_BLOCKS) > 0 ? tunable(TUNE_SEL_BLOCKS) : device_cus();
+    if (blocks > cap) blocks = cap;  // (one 1024-thread block per CU: every block flushes its non-empty bins with global atomics)
     if (blocks < 1) blocks = 1;
     const uint16_t* s16 = reinterpret_cast<const uint16_t*>(scores);
     ProfScope ps("select", stream);  // the streaming passes
@@ -473,7 +478,7 @@ static int select_threshold_impl(const void* scores, int64_t n, double ratio, in
     // rows whose start is not 16-byte aligned take the scalar path inside the kernel (row_len % 8 != 0)
     const int64_t per_row_vec = ((row_len & 7) == 0) ? (row_len >> 3) : row_len;
     int bx = (int)((per_row_vec + HIST_THREADS - 1) / HIST_THREADS);
-    int max_bx = (int)(tunable(TUNE_EMIT_BLOCKS) / rows);
+    int max_bx = (int)((tunable(TUNE_EMIT_BLOCKS) > 0 ? tunable(TUNE_EMIT_BLOCKS) : device_cus()) / rows);
     if (max_bx < 1) max_bx = 1;
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;

@@ -220,6 +220,14 @@ class _CacheBase(KVScore):
             valid, thres_dev, kept_dev, _ = self._threshold_device(score, ratio, prehist=hist if score is buf else None)
             self.valid = valid.view(score.shape)
             host = torch.stack([thres_dev.double().squeeze(0), kept_dev.double().squeeze(0)]).cpu()  # one D2H sync
+            if hist is not None and ratio < 1 and host[0] != host[0]:
+                # a NaN threshold out of the pre-built histogram: either the scores hold NaNs (legitimate: the plain path says the
+                # same) or the histogram was not of these scores (the kernels then flag the lost rank with NaN, kvz_select.hip)
+                valid, thres_dev, kept_dev, _ = self._threshold_device(score, ratio)
+                plain = torch.stack([thres_dev.double().squeeze(0), kept_dev.double().squeeze(0)]).cpu()
+                if plain[0] == plain[0]:
+                    raise ops.KvzError("selection: the histogram built by the finalize launch does not belong to these scores")
+                self.valid, host = valid.view(score.shape), plain
             thres = float(host[0]) if ratio < 1 else 0.
             kept = int(host[1])
             n = self.valid.numel()

@@ -25,6 +25,7 @@ import torch
 
 from .kvcache import EvictCache, RetainCache
 from .monkeypatch import replace_attn
+from .ops import KvzError
 from .template import template
 
 
@@ -63,9 +64,7 @@ def _on_model_device(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *args, **kwargs):
-        dev = self.device
-        if dev.type != "cuda":
-            return fn(self, *args, **kwargs)
+        dev = self.device   # (always a GPU: __init__ refuses anything else)
         with torch.cuda.device(dev):
             return fn(self, *args, **kwargs)
     return wrapped
@@ -83,7 +82,10 @@ class ModelKVzip:
             tokenizer = tokenizer or AutoTokenizer.from_pretrained(model)
             # ONE device: a cache object (side streams, events, workspaces) lives on one GPU, and the multi-GPU scheme of this path is
             # one context per GPU (kvzip_amd/dist.py), not one model sharded over several
-            dev = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
+            if not torch.cuda.is_available():
+                raise KvzError("ModelKVzip needs a GPU: the hot path (dense and post-prune attention, scoring, selection, compaction) "
+                               "runs on the library's HIP kernels only, there is no CPU implementation")
+            dev = f"cuda:{torch.cuda.current_device()}"
             model = AutoModelForCausalLM.from_pretrained(model, torch_dtype="auto", device_map=dev).eval()
         else:
             replace_attn(name or type(model).__name__)
@@ -95,6 +97,9 @@ class ModelKVzip:
         self.name = name or type(model).__name__
         self.dtype = next(model.parameters()).dtype
         self.device = next(model.parameters()).device
+        if self.device.type != "cuda":   # (fail HERE, not at the first forward inside kvzip_amd.attn)
+            raise KvzError(f"ModelKVzip: the model lives on {self.device}; the product path has no CPU implementation - move it to the GPU "
+                           "(model.to('cuda')) before wrapping it")
         self.config = model.config
         self.config._attn_implementation = "kvzip_hip"  # dense path through kvzip_amd.attn, no HF mask construction
         self.kv_type = kv_type

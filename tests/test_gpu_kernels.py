@@ -59,6 +59,22 @@ def test_select_threshold_vs_oracle(dtype, shape):
         assert torch.equal(rows, want_v.view(-1, shape[-1]).sum(-1).int())
 
 
+def test_select_prehist_with_a_foreign_histogram_is_flagged():
+    """``kvz_select_threshold_prehist`` trusts that the workspace holds the histogram of exactly these scores.  When
+    it does not (here: an all-zero histogram, so the wanted rank lies beyond its total) the kernels must not turn uninitialised LDS
+    into a threshold: the threshold comes back NaN and nothing is kept (``EvictCache._select`` then re-runs the plain path and raises)."""
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    score = (torch.rand(4, 1, 2, 1024, generator=g) ** 3).to(torch.float16).to(DEV)
+    ws = o.select_workspace(DEV)
+    ws.zero_()
+    valid, thres, kept, rows = o.select_threshold(score, 0.3, row_len=1024, prehist=ws)
+    assert torch.isnan(thres).all() and int(kept.item()) == 0 and not bool(valid.any())
+    valid, thres, kept, rows = o.select_threshold(score, 0.3, row_len=1024)          # the plain path on the same scores
+    want, wt = orc.threshold(score.cpu(), 0.3)
+    assert float(thres.item()) == wt and torch.equal(valid.cpu(), want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("n_rows,row_len,holes", [(8, 4096, False), (6, 1000, True), (1, 13, True), (3, 2001, False)])
 def test_finalize_log_with_histogram_then_select(dtype, n_rows, row_len, holes):
