@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 # What the matrix pipe reaches on RANDOM fp16 operands on this part: the package sits at its power limit and the clock follows the
 # energy per cycle - v_mfma_f32_32x32x16_f16 back to back on every SIMD runs at 1.65 GHz (19.7 ns per MFMA) instead of 2.21 GHz with
-# constant operands (tools/probe_pipe.hip, profiles/r5_scoring_attribution.txt item 5).  Reported beside the spec peak, never instead.
+# constant operands (tools/probes/probe_pipe.hip, profiles/r5_scoring_attribution.txt item 5).  Reported beside the spec peak, never instead.
 MFMA_RANDOM_DATA_TFLOPS = 1720.0
 CLOCK_UNDER_SCORING_GHZ = 1.95  # SQ_WAVE_CYCLES x 4 / waves / launch duration of the scoring kernels (same file, item 1)
 

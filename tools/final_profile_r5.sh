@@ -51,6 +51,8 @@ PY
   head -c 1500 $O/pmc_summary.json; cat $O/pmc_durations.txt
 fi
 if [ $part = probes ]; then
+  mkdir -p tools/bin
+  for p in probe_pipe probe_coexec; do [ -x tools/bin/$p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/$p.hip -o tools/bin/$p 2> /dev/null; done
   for s in 0 12345; do tools/bin/probe_pipe $s > $O/probe_pipe_seed$s.txt 2>&1; done
   tools/bin/probe_coexec > $O/probe_coexec.txt 2>&1
   python tools/zero_score_probe.py > $O/zero_score_probe.txt 2>&1

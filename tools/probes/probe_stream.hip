@@ -5,7 +5,7 @@
 //          instruction) + V contiguous;   PAT 1: everything contiguous (1 KiB per wave instruction)
 //   DEPTH: tiles (32 keys = 16 KiB of K+V per wave) requested ahead of the one being consumed
 //   blocks x waves: 176 / 256 x 8 (one block per CU), 512 x 4 and 512 x 8 (two per CU)
-// build: hipcc --offload-arch=gfx950 -O3 tools/probe_stream.hip -o tools/probe_stream
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/probe_stream.hip -o tools/probe_stream
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
