@@ -163,7 +163,9 @@ int kvz_select_threshold(const void* scores, int64_t n, double ratio, int dtype,
                          float* thres_dev, int64_t* kept_dev,
                          void* ws, size_t ws_bytes, kvz_stream_t stream);
 /* The same selection when `ws` already holds the first histogram of exactly these scores (kvz_score_finalize_log_hist): two launches
- * (low-bits histogram, mask) instead of three.  Same results, bit for bit. */
+ * (low-bits histogram, mask) instead of three.  Same results, bit for bit.  A workspace whose histogram does NOT belong to these
+ * scores (the wanted rank lies beyond its total) gives *thres_dev = NaN and an all-false mask - never a threshold read from
+ * uninitialised memory; a caller that sees NaN without NaN scores falls back to kvz_select_threshold (EvictCache._select does). */
 int kvz_select_threshold_prehist(const void* scores, int64_t n, double ratio, int dtype,
                                  uint8_t* valid_out,
                                  int64_t row_len, int32_t* row_counts,
