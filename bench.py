@@ -75,7 +75,7 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group even with one GPU and push the result gather and the max-over-ranks "
                          "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
-    ap.add_argument("--score-streams", type=int, default=3,
+    ap.add_argument("--score-streams", type=int, default=2,
                     help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
     args = ap.parse_args(argv)
     if args.ratio is None:
@@ -682,7 +682,7 @@ def _run(args):
         },
         "roofline": roofline,
         "roofline_stages": stages,
-        "decode": {"tokens_per_s": T / t_dec, "ms_per_token": t_dec / T * 1e3, "tokens": T,
+        "decode": {"tokens_per_s": (T / t_dec) if T else None, "ms_per_token": (t_dec / T * 1e3) if T else None, "tokens": T,
                    "ms_per_token_hip_graph": (t_graph / T * 1e3) if t_graph else None,
                    "what": "per token: L x (O(1) append of K,V + variable-length attention), model MLP/projections excluded; "
                            "ms_per_token = the step issued layer by layer from Python (kv.update_attend, what kvzip_amd.attn does), "

@@ -9,9 +9,10 @@ Differences that are deliberate (and invisible through the interface):
   * ``_threshold_uniform`` breaks ties towards the lowest index (``torch.topk`` leaves it unspecified);
   * ``_get_score`` is ASYNCHRONOUS with respect to the caller's stream: the scores of a layer are a side product that
     nothing in the forward pass consumes, so the kernels of consecutive layers are issued round-robin on
-    ``n_score_streams`` (default 3) side streams.  The tail of one persistent kernel, the launch gaps and the two tiny
-    merge / finalize kernels of a call then overlap with the big kernels of the next ones (+16 % scoring throughput on
-    MI355X with two streams, a further +4 % with three; a fourth finds no independent hardware queue and costs 15 %).  Ordering is kept with events: the side stream waits for the caller's stream (inputs), ``update`` of a layer
+    ``n_score_streams`` (default 2) side streams.  The tail of one persistent kernel, the launch gaps and the two tiny
+    merge / finalize kernels of a call then overlap with the big kernels of the next ones (+9 % scoring throughput on
+    MI355X with two streams; round 5, same boxes: three streams are 3-4.5 % SLOWER than two, four 7 % - rounds 2-3 had measured
+    three ahead when a call still had a separate merge launch).  Ordering is kept with events: the side stream waits for the caller's stream (inputs), ``update`` of a layer
     waits for that layer's previous scoring call (it overwrites the rows that call read), and reading ``.score``,
     thresholding or pruning waits for everything outstanding.
 """
@@ -117,7 +118,7 @@ class KVScore:
         self._score_fill: List[int] = []
         self._score_ws: List[Optional[torch.Tensor]] = []
         self._ws_need = {}             # (q_len, m, H) -> workspace bytes
-        self.n_score_streams = 3       # 1 = score on the caller's stream
+        self.n_score_streams = 2       # 1 = score on the caller's stream (round 5: two side streams beat three by 3-4.5 % on three boxes, profiles/r5_streams_ab.txt)
         self._score_exclusive = False  # True: the next calls run alone on the caller's stream (clean kernel timings)
         self._score_side: List["torch.cuda.Stream"] = []
         self._async = -1               # handle of the library's asynchronous-scoring context (events per layer)
