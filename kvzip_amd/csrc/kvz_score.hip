@@ -282,6 +282,20 @@ __device__ static inline void quad_args(float a0, float a1, float a2, float a3, 
 // forwarding hazard: 1 wait state).  Hand-placed v_pk_add_f32 on a register pair (two instead of four additions, 78 instead
 // of 89 VALU instructions per block, bit-identical sums) is 1.5 % SLOWER in the scoring loop (round 4, same box): a plain fp32
 // VOP2 issues in 2.5 cycles on this part, the packed form does not, and the pair adds a dependent chain.
+// first quad of a step: the partial sums are WRITTEN (e0 + e2, e1 + e3) - the same values as ((0 + e0) + e2), ((0 + e1) + e3), two v_add
+// and two v_mov fewer per 32x32 block
+__device__ static inline void quad_sum_first(const float (&arg)[4], float& ps0, float& ps1) {
+    float e0, e1, e2, e3;
+    asm("v_exp_f32 %[e0], %[a0]\n\t"
+        "v_exp_f32 %[e1], %[a1]\n\t"
+        "v_exp_f32 %[e2], %[a2]\n\t"
+        "v_exp_f32 %[e3], %[a3]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32 %[p0], %[e0], %[e2]\n\t"
+        "v_add_f32 %[p1], %[e1], %[e3]"
+        : [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3), [p0] "=&v"(ps0), [p1] "=&v"(ps1)
+        : [a0] "v"(arg[0]), [a1] "v"(arg[1]), [a2] "v"(arg[2]), [a3] "v"(arg[3]));
+}
 __device__ static inline void quad_sum(const float (&arg)[4], float& ps0, float& ps1) {
     float e0, e1, e2, e3;
     asm("v_exp_f32 %[e0], %[a0]\n\t"
@@ -660,7 +674,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
     // the CURRENT block (accc, first key k0).  WITH_MFMA = false drains the pipeline (last block of an item).  `hook` runs
     // after the first quarter of the step (fragment prefetch / tile hand-over): by then the last MFMA of the previous step
     // has read the fragment registers that the prefetch overwrites.
-    auto step = [&](f16v (&accn)[PA_RG], const f16v (&accc)[PA_RG], const u32x4 (&frn)[C::KK], int k0, float ps_low, auto mask_tag,
+    // (ps_low: a float, or std::false_type where the lower bound is known to be 0 - steps 1-3 of a tile: one compare and one scalar OR less)
+    auto step = [&](f16v (&accn)[PA_RG], const f16v (&accc)[PA_RG], const u32x4 (&frn)[C::KK], int k0, auto ps_low, auto mask_tag,
                     auto mfma_tag, auto&& hook) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr bool WITH_MFMA = decltype(mfma_tag)::value;
@@ -669,7 +684,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         int rel[PA_RG];
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g) {
-            ps0[g] = ps1[g] = 0.f;
             rel[g] = rows.limit[g] - (k0 + 4 * half);  // key offset (i&3)+8*(i>>2) of accumulator i is visible iff <= rel
         }
 #pragma unroll
@@ -708,7 +722,10 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
                     }
             }
 #pragma unroll
-            for (int g = 0; g < PA_RG; ++g) quad_sum(arg[g], ps0[g], ps1[g]);
+            for (int g = 0; g < PA_RG; ++g) {
+                if (qd == 0) quad_sum_first(arg[g], ps0[g], ps1[g]);
+                else quad_sum(arg[g], ps0[g], ps1[g]);
+            }
             if (qd == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 hook();
@@ -718,7 +735,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
 #pragma unroll
         for (int g = 0; g < PA_RG; ++g) {
             float ps = ps0[g] + ps1[g];
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ps <= PA2_SUM_LIMIT) || ps < ps_low) != 0, 0)) {  // wave-uniform and rare: move the reference, redo
+            bool off = !(ps <= PA2_SUM_LIMIT);
+            if constexpr (std::is_same<decltype(ps_low), float>::value) off = off || ps < ps_low;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(off) != 0, 0)) {  // wave-uniform and rare: move the reference, redo
                 asm volatile("" ::: "memory");                                                 // (keeps it a branch)
                 const float tmax = max_packed16<T>(xp[g]);
                 // up: a logit far above the reference; down (first block of an item only, nothing summed yet): all logits far below
@@ -783,13 +802,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_ke
         if (young) __builtin_amdgcn_s_setprio(1);
         step(acc[1], acc[0], fr[1], k0, (t == cur.t_lo) ? PA2_SUM_LOW : 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[0], b_tag, I2{}); });
         if (young) __builtin_amdgcn_s_setprio(0);
-        step(acc[0], acc[1], fr[0], k0 + 32, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
+        step(acc[0], acc[1], fr[0], k0 + 32, std::false_type{}, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { load_frags(fr[1], b_tag, I3{}); });
         if (young) __builtin_amdgcn_s_setprio(1);
-        step(acc[1], acc[0], fr[1], k0 + 64, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
+        step(acc[1], acc[0], fr[1], k0 + 64, std::false_type{}, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
         if (young) __builtin_amdgcn_s_setprio(0);
         // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
         // (one variant less of every tile body; the matrix pipe has the slack)
-        step(acc[0], acc[1], fr[0], k0 + 96, 0.f, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) {
+        step(acc[0], acc[1], fr[0], k0 + 96, std::false_type{}, mask_tag, std::true_type{}, [&]() __attribute__((always_inline)) {
             if (next_ready) load_frags(fr[1], std::integral_constant<int, B1>{}, I1{});
         });
     };
