@@ -89,7 +89,7 @@ static void prof_collect() {
 
 // ---- tuning knobs --------------------------------------------------------------------------------------------------------
 namespace kvz {
-static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "sel_blocks", "emit_blocks", "flash2_split"};
+static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "sel_blocks", "emit_blocks", "flash2_split", "score_prune"};
 // attn_items: work items the key ranges of a decode call are cut into; 0 (default) = 256 - Hkv, see kvz_attn.hip:attn_items
 //   (round 2 measured 128 / 192 / 256 / 384 on an infinity-cache-resident probe, profiles/r2_attn_items.txt; round 4 on cold HBM);
 // flash_min_rows: query rows per head above which the multi-row kernels take over from the split-key decode kernel;
@@ -100,8 +100,10 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 // sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (default 0 =
 //   one per CU, device_cus(): every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
-static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}};   // (atomic: a probe may flip a knob while another thread launches)
+// score_prune: 0 = two full passes over Q.K^T (default); 1 = key-per-lane pass A (score_rowstatT_kernel), pass B over every block;
+//   2 = pass B only over the (32-row group, 32-key block) pairs the bounds of pass A cannot rule out (fp16, deferred-log path).
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 0};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {0}};   // (atomic: a probe may flip a knob while another thread launches)
 int tunable(Tunable t) { return g_tune[t].load(std::memory_order_relaxed); }
 int device_cus() {
     static const int n = [] {

@@ -28,6 +28,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -58,6 +59,16 @@ struct ScoreArgs {
     FastDiv dq, dh;      // q_len, Hkv
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
+    // ---- exact pruning of pass B (round 5: score_rowstatT2_kernel, score_merge_kernel, score_bounds2_kernel, score_colmax_sparse_kernel)
+    uint16_t* colu;      // [Hkv, nkb, n_groups, 32] (+ 64 spare bytes)  16-bit patterns of u_gj = max over the 32 rows of group g of the logit x_rj
+    float2* gbound;      // [Hkv, n_groups]     (max, min) over the rows of group g of  n_r = -(m_r + log l_r);  (NaN, NaN): a row with NaN statistics
+    float* nrow;         // [Hkv, 32 n_groups]  n_r per query row (-inf for the padding rows of the last group)
+    uint32_t* entries;   // compacted candidate pairs: g | kb << 11 | h << 25, the pairs of one (h, kb) contiguous
+    uint32_t* counter;   // [1] number of entries (zeroed by score_merge_kernel, filled by score_bounds2_kernel)
+    int n_groups, nkb;
+    int all_pairs;       // (debug knob: every pair is a candidate)
+    uint32_t* fallback;  // [1] id of the last call whose key-per-lane pass A met a logit outside its safe range (ids only grow: never reset)
+    uint32_t call_id;    // this call's id (host counter, > 0)
 };
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
@@ -426,8 +437,11 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
     return true;
 }
 
-template <typename T, int D, bool FAST>
+template <typename T, int D, bool FAST, bool FB = false>   // FB: the fallback launch behind the key-per-lane pass - runs only if that pass flagged this call
 __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a, PaPlan plan) {
+    if constexpr (FB) {
+        if (*a.fallback != a.call_id) return;
+    }
     constexpr int NWAVES = PA_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
@@ -945,8 +959,11 @@ __device__ static inline float2 merge_row_stats(const float2* __restrict__ stats
     const float delta = __builtin_fmaf(M, L2E, -ML2);
     return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
-template <typename T, int D, bool FAST>
+template <typename T, int D, bool FAST, bool FB = false>   // (FB: the fallback launch, see score_rowstat2_kernel)
 __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a) {
+    if constexpr (FB) {
+        if (*a.fallback != a.call_id) return;
+    }
     constexpr int NWAVES = PB_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
@@ -1288,6 +1305,879 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
     }
 }
 
+// ---- pass A with one KEY per lane, exact pruning of pass B (round 5) ---------------------------------------------------------------------
+// score_rowstatT2_kernel is score_rowstat2_kernel with the MFMA operands swapped: the 32 query rows of a wave are the A operand (registers),
+// key tiles stream through the LDS ring as the B operand, so a lane holds ONE key and its 16 accumulators are 16 query rows
+// (k -> row (k & 3) + 8 (k >> 2) + 4 half).  Row sums become 16 lane-partial accumulators, reduced across lanes once per item; what the layout
+// buys is the per-key maximum over the 32 rows of the wave - lane-local over the 16 registers plus one half swap - written as u[g][j] for
+// the ctx keys.  With n_r = -(m_r + log l_r):   max_{r in g} (x_rj + n_r) <= u_gj + max_g n   and   t_j >= max_g (u_gj + min_g n),
+// so the column maximum t_j only has to be recomputed for the (32-row group, 32-key block) pairs that bound cannot rule out - exactly (the
+// bounds use the fp32 addition the recomputation applies to a logit and a row's statistic, monotone in both arguments): 18 % of the pairs
+// on the benchmark's Gaussian logits, 3-21 % on copy-like prompts (tools/prune_bound_sim.py).  score_merge_kernel merges the partial
+// statistics into n_r and the group bounds, score_bounds2_kernel compacts the candidate pairs, score_colmax_sparse_kernel recomputes them.
+
+// first half of the rounding chain for four logits: x = half(float(half(acc)) * rcp) (FAST) or the division; packed results only
+template <typename T, bool FAST>
+__device__ static inline void quad_round(float a0, float a1, float a2, float a3, uint32_t& xa, uint32_t& xb, float c, float rcp) {
+    if constexpr (std::is_same<T, _Float16>::value && FAST) {
+        float g0, g1, g2, g3;
+        asm("v_cvt_pk_f16_f32 %[xa], %[a0], %[a1]\n\t"
+            "v_cvt_pk_f16_f32 %[xb], %[a2], %[a3]\n\t"
+            "v_fma_mix_f32 %[g0], %[xa], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[r], 0 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_pk_f16_f32 %[xa], %[g0], %[g1]\n\t"
+            "v_cvt_pk_f16_f32 %[xb], %[g2], %[g3]"
+            : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3)
+            : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp));
+    } else {
+        const T x0 = round_chain_h<T, FAST>(a0, c, rcp), x1 = round_chain_h<T, FAST>(a1, c, rcp);
+        const T x2 = round_chain_h<T, FAST>(a2, c, rcp), x3 = round_chain_h<T, FAST>(a3, c, rcp);
+        xa = bits16(x0) | (bits16(x1) << 16);
+        xb = bits16(x2) | (bits16(x3) << 16);
+    }
+}
+// second half: exponent arguments x * log2e + n_k with one addend per logit (four different rows), the four exponentials
+template <typename T>
+__device__ static inline void quad_exp4(uint32_t xa, uint32_t xb, float L2E, float n0, float n1, float n2, float n3, float (&e)[4]) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        float g0, g1, g2, g3;
+        asm("v_fma_mix_f32 %[g0], %[xa], %[l2e], %[n0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[n2] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[n1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[n3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_exp_f32 %[e0], %[g0]\n\t"
+            "v_exp_f32 %[e2], %[g2]\n\t"
+            "v_exp_f32 %[e1], %[g1]\n\t"
+            "v_exp_f32 %[e3], %[g3]"
+            : [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+            : [xa] "v"(xa), [xb] "v"(xb), [l2e] "v"(L2E), [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2), [n3] "v"(n3));
+    } else {
+        e[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xa), L2E, n0));
+        e[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xa), L2E, n1));
+        e[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xb), L2E, n2));
+        e[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xb), L2E, n3));
+    }
+}
+// maximum of the two 16-bit halves of eight packed registers, as fp32 (NaN propagates: v_pk_maximum3_f16)
+__device__ static inline uint32_t pk_max8(const uint32_t (&xp)[8]) {
+    uint32_t m;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(xp[0]), "v"(xp[1]), "v"(xp[2]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[3]), "v"(xp[4]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[5]), "v"(xp[6]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %2" : "=v"(m) : "v"(m), "v"(xp[7]));
+    return m;
+}
+
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_kernel(ScoreArgs a, PaPlan plan) {
+    constexpr int NWAVES = PA_WAVES;
+    typedef ScoreCfg<D> C;
+    typedef typename Mfma32<T>::v8 v8;
+    constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
+    constexpr int RING = 3;  // key-tile buffers: tile p of the block's stream lives in buffer p % 3 (160 KiB of LDS at D = 128)
+    __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
+    constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
+    constexpr float L2E = 1.44269504088896340736f;
+    constexpr int NB = SC_TILE / 32;  // 32-key blocks per tile
+    static_assert(NB == 4, "the block pipeline alternates two register sets over an even number of blocks per tile");
+
+    const int R = a.G * a.q_len;
+    const int KT = a.sink + a.m + a.q_len;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int diag0 = a.sink + a.m;  // first key that can be masked for some row
+    const int off_ctx = a.start - a.sink;                       // virtual -> cache row, ctx segment
+    const int off_rep = a.klen - a.q_len - a.sink - a.m;        // virtual -> cache row, repeat segment
+    const uint32_t lane_off = stage_lane_offset<D, NWAVES>(wave, lane);
+
+    struct Item { int k, h, rt, z, t_lo, t_hi; };  // unit, KV head, row tile, ordinal of the partial, key tiles [t_lo, t_hi)
+    // exactly balanced static partition (PaPlan): this block's range of the tile sequence, walked as segments; Item.k = unit
+    const int u_first = plan.unit[blockIdx.x], t_first = plan.tile[blockIdx.x];
+    const int u_end = plan.unit[blockIdx.x + 1], t_end = plan.tile[blockIdx.x + 1];  // exclusive: (u_end, t_end)
+    int ord0 = 0;  // ordinal of the first segment inside its unit = earlier blocks that also started inside it (+ the opener)
+    if (t_first > 0) {
+        ord0 = 1;
+        for (int bb = (int)blockIdx.x - 1; bb > 0 && plan.unit[bb] == u_first && plan.tile[bb] > 0; --bb) ++ord0;
+    }
+    auto item_from = [&](int u) -> Item {
+        Item it;
+        it.k = u; it.h = it.rt = it.z = 0; it.t_lo = it.t_hi = 0;
+        if (u > u_end || (u == u_end && t_end == 0)) return it;
+        it.rt = a.dh.div(u);
+        it.h = u - it.rt * a.n_kv_heads;
+        const int r0 = it.rt * PA_ROWS, r1 = min(R - 1, r0 + PA_ROWS - 1);
+        const int h0 = a.dq.div(r0), h1 = a.dq.div(r1);
+        const int qmax = (h0 == h1) ? (r1 - h1 * a.q_len) : (a.q_len - 1);
+        const int ntiles = (a.sink + a.m + qmax + 1 + SC_TILE - 1) / SC_TILE;
+        it.t_lo = (u == u_first) ? t_first : 0;
+        it.t_hi = (u == u_end) ? t_end : ntiles;
+        it.z = (u == u_first) ? ord0 : 0;
+        return it;
+    };
+    const int first_item = u_first;
+    auto valid = [](const Item& it) { return it.t_lo < it.t_hi; };
+    // tiles (128 consecutive virtual keys) that lie inside ONE segment are consecutive rows of the cache: [tc_lo, tc_hi) inside
+    // the ctx chunk, [tr_lo, tr_hi) inside the repeat chunk, [0, ts_hi) inside the sink; every other tile straddles a boundary
+    // (or the end) and takes the per-lane path
+    const int ts_hi = a.sink / SC_TILE;
+    const int tc_lo = (a.sink + SC_TILE - 1) / SC_TILE, tc_hi = (a.sink + a.m) / SC_TILE;
+    const int tr_lo = (a.sink + a.m + SC_TILE - 1) / SC_TILE, tr_hi = KT / SC_TILE;
+    const uint32_t lds0 = lds_addr(lds);
+    const char* const kbase = reinterpret_cast<const char*>(a.k);
+    const int64_t khs = a.k_head_stride * 2;
+    auto stage = [&](int b, int h, int t) __attribute__((always_inline)) {
+        const uint32_t dst = lds0 + (uint32_t)(b * C::TILE_BYTES);
+        const char* kh = kbase + (int64_t)h * khs;
+        const int kv0 = t * SC_TILE;
+        int off = 0;
+        bool linear = true;
+        if (t >= tc_lo && t < tc_hi) off = off_ctx;
+        else if (t >= tr_lo && t < tr_hi) off = off_rep;
+        else if (t >= ts_hi) linear = false;
+        if (linear) {
+            stage_tile_linear_a<D, NWAVES>(dst, kh + (int64_t)(kv0 + off) * C::ROW_BYTES, lane_off, wave);
+        } else {  // (inlined: a call would open with s_waitcnt vmcnt(0) and drain the tiles in flight)
+            constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+            // (this kernel has no register to spare for loop-invariant per-lane offsets of a path taken three times per item: the lane id
+            // is made opaque here, so the offsets are computed where they are used instead of being hoisted - and spilled)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int ci = i * NWAVES + wave;  // wave-uniform 1-KiB piece of the tile
+                const int row = ci * ROWS_PER_INSTR + lane_o / C::CPR;
+                const int pch = lane_o % C::CPR;
+                const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                const int kv = min(kv0 + row, KT - 1);
+                const int crow = kv + (kv < a.sink ? 0 : (kv < a.sink + a.m ? off_ctx : off_rep));
+                lds_dma16a(kh, (uint32_t)(crow * C::ROW_BYTES + chunk * 16), dst + (uint32_t)(ci * 1024));
+            }
+        }
+    };
+    auto stage_q = [&](const Item& it) __attribute__((always_inline)) {
+        // 32 rows per group, same swizzle as a key tile; rows beyond R shadow row R-1.  The rows of a group lie in at most
+        // two query heads of the KV head: one scalar division per group, none per lane.  (Inlined: a call drains the DMA queue.)
+        const char* qh = reinterpret_cast<const char*>(a.q) + (int64_t)it.h * a.G * a.q_head_stride * 2;
+        const int64_t hs = a.q_head_stride * 2;
+        constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            const uint32_t buf = lds0 + (uint32_t)(RING * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
+            const int r0 = it.rt * PA_ROWS + (wave * PA_RG + g) * 32;
+            const int rc0 = min(r0, R - 1);
+            const int g0 = a.dq.div(rc0), qi0 = rc0 - g0 * a.q_len;  // wave-uniform
+            if (a.q_len >= 32) {
+                // at most two query heads per group: a wave-uniform base, a shift for the row and one select for the rows that
+                // belong to the next head - no per-lane multiply or division (the generic form below costs ~38 instructions per
+                // piece, 1 500 cycles per item switch in the in-kernel timeline)
+                const uint32_t base = (uint32_t)(g0 * (int)hs + qi0 * C::ROW_BYTES);
+                const uint32_t wrapd = (uint32_t)((int)hs - a.q_len * C::ROW_BYTES);
+                const int nfirst = a.q_len - qi0;  // rows of the group that still lie in head g0
+                const int tail = R - 1 - rc0;      // rows beyond the last one shadow it
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));   // (not hoisted: see stage)
+                const int lrow = lane_o / C::CPR, pch = lane_o % C::CPR;
+#pragma unroll
+                for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+                    const int row = i * ROWS_PER_INSTR + lrow;
+                    const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                    const int rowc = min(row, tail);
+                    const uint32_t voff = base + (uint32_t)(rowc * C::ROW_BYTES + chunk * 16) + (rowc >= nfirst ? wrapd : 0u);
+                    lds_dma16a(qh, voff, buf + (uint32_t)(i * 1024));
+                }
+            } else {  // (tiny chunks only: a group of 32 rows spans several query heads)
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+#pragma unroll
+                for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+                    const int row = i * ROWS_PER_INSTR + lane_o / C::CPR;
+                    const int pch = lane_o % C::CPR;
+                    const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                    int gg = g0, qi = qi0 + min(row, R - 1 - rc0);  // clamp to the last row
+                    const int dg = a.dq.div(qi);
+                    gg += dg;
+                    qi -= dg * a.q_len;
+                    lds_dma16a(qh, (uint32_t)(gg * (int)hs + qi * C::ROW_BYTES + chunk * 16), buf + (uint32_t)(i * 1024));
+                }
+            }
+        }
+    };
+    FragAddr<D> fa0;
+    fa0.init(lds, l31, half);
+    auto read_q = [&](v8 (&dst)[PA_RG][C::KK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < PA_RG; ++g) {
+            FragAddr<D> fq;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) fq.a[kk] = fa0.a[kk] + (uint32_t)(RING * C::TILE_BYTES + (wave * PA_RG + g) * QG_BYTES);
+            u32x4 tmp[C::KK];
+            frag_load<D>(tmp, fq, 0);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) dst[g][kk] = __builtin_bit_cast(v8, tmp[kk]);
+        }
+    };
+    // ONE set of fragment registers (the row-per-lane kernel has two): fragment kk of block n + 2 is read into the registers of fragment kk of
+    // block n + 1 as soon as the MFMA that consumed them has been issued - the 32 registers are where the 16 per-row sums and addends of
+    // this layout live
+    typedef const __attribute__((address_space(3))) u32x4* lds_frag_t;
+    auto load_frag1 = [&](u32x4& dst, auto b_tag, auto kb_tag, int kk) __attribute__((always_inline)) {
+        constexpr int off = decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES;
+        dst = *(lds_frag_t)(uintptr_t)(fa0.a[kk] + off);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    Item cur = item_from(first_item);
+    if (!valid(cur)) return;
+    Item nxt = item_from(cur.k + 1);
+    bool sq_in_next = false, sq_done = false;
+    int sq_t = cur.t_lo;
+    auto sq_stage = [&](int b) __attribute__((always_inline)) {
+        stage(b, sq_in_next ? nxt.h : cur.h, sq_t);
+        ++sq_t;
+        if (sq_t >= (sq_in_next ? nxt.t_hi : cur.t_hi)) {
+            if (!sq_in_next && valid(nxt)) {
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            } else {
+                sq_done = true;
+            }
+        }
+    };
+    stage_q(cur);
+    sq_stage(0);
+    int staged = 1;  // tiles of the block's stream staged so far (stream position p -> buffer p % 3)
+    if (!sq_done) {
+        sq_stage(1);
+        staged = 2;
+    }
+    // the query rows and the first tile are needed now, the second tile at the first hand-over (which waits for it)
+    if (staged == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else stage_wait();
+    block_barrier();
+    v8 bq[PA_RG][C::KK];
+    read_q(bq);
+    u32x4 fr[C::KK];
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) load_frag1(fr[kk], I0{}, I0{}, kk);
+#pragma unroll
+    for (int g = 0; g < PA_RG; ++g)
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+            asm volatile("" : "+v"(bq[g][kk]));  // the rows are in registers: the area is free
+        }
+    if (valid(nxt)) stage_q(nxt);
+
+    int pbuf = 0;  // buffer of the tile being computed (= sp % 3)
+    int sp = 0;    // its position in the block's stream
+    int t = cur.t_lo;
+    // per-row state of the lane's 16 rows (accumulator k = row (k & 3) + 8 (k >> 2) + 4 half of the wave's group): lane-partial sum of
+    // 2^(x log2e + nm) and the addend nm = -fl(ref * log2e).  The references are LANE-PRIVATE: a lane sees one key per block, its 16 rows take
+    // their logits of the item's first block as references (init_refs), so nothing crosses lanes inside the loop; the 32 lanes of a half are
+    // merged like partial statistics when the item ends.  References never move inside the pipeline: a logit more than SAFE above the lane's
+    // smallest reference flags the whole call for the fallback (the row-per-lane kernels), see the end of the kernel.
+    constexpr float RL2E = 0.69314718055994530942f;
+    float lsum[16], nm[16];
+    float nm_max;   // max_k nm[k] = -(smallest reference) * log2e: x * log2e + nm_max <= SAFE * log2e keeps every exponential below 2^(SAFE log2e)
+    constexpr float SAFE_L2 = 40.f * L2E;     // e^40 x 4 058 keys: far inside fp32; a logit that far above a row's first one is rare
+    bool viol = false;   // (per lane, sticky) some logit was out of the safe range
+    int wmin, t_hidden;   // keys <= wmin are visible to every row of the wave; t_hidden: first tile that no row of this wave sees
+    int mask_a0, mask_w, mask_qiw;   // causal mask of the wave's group (see step)
+    const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
+    uint32_t u_spare;                // byte offset (from urow) of the spare row behind the array
+    auto start_item = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lsum[k] = 0.f;   // (nm, nm_max: init_refs, behind the item's first chain)
+        const int r0 = cur.rt * PA_ROWS + wave * 32;
+        const int rc0 = min(r0, R - 1), last = min(r0 + 31, R - 1);
+        const int qi0 = a.dq.mod(rc0), n = last - rc0;
+        const bool wraps = qi0 + n >= a.q_len;
+        wmin = a.sink + a.m + (wraps ? 0 : qi0);
+        t_hidden = max((a.sink + a.m + (wraps ? a.q_len - 1 : qi0 + n)) / SC_TILE + 1, cur.t_lo + 1);
+        // with d = kv - sink - m the rows before the wrap into the next query head (i < iw) see key kv iff i >= d - qi0, the rows after it
+        // iff i >= d + iw; rows beyond the last one (they shadow it) get the mask of the positions they would have - never stored
+        const int iw = wraps ? a.q_len - qi0 : 64;
+        mask_a0 = -a.sink - a.m - qi0;   // + k0 + (lane & 31) - 4 half -> d - qi0 - 4 half
+        mask_w = iw;                     // - 4 half
+        mask_qiw = qi0 + iw;
+        urow = a.colu + ((int64_t)cur.h * a.nkb * a.n_groups + (cur.rt * PA_WAVES + wave)) * 32;
+        u_spare = (uint32_t)((((int64_t)a.n_kv_heads - cur.h) * a.nkb * a.n_groups - (cur.rt * PA_WAVES + wave)) * 64) + (uint32_t)(l31 * 2);
+    };
+    start_item();
+
+    // visibility bits of this lane's key k0 + (lane & 31) for the 16 rows (bit c_k): the general form, all ones where nothing is hidden
+    auto vis_bits = [&](int k0) __attribute__((always_inline)) -> uint32_t {
+        auto ones_from = [](int x) __attribute__((always_inline)) -> uint32_t { return x >= 32 ? 0u : (0xFFFFFFFFu << max(x, 0)); };
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int h4 = (lane_o >> 5) * 4;
+        const int mask_a = mask_a0 + k0 + (lane_o & 31) - h4, mw = mask_w - h4, mask_b = max(mask_a + mask_qiw, mw);
+        return (ones_from(mask_a) & ~ones_from(mw)) | ones_from(mask_b);
+    };
+    f16v acc[2];
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma_step = [&](f16v& accn, int kk) __attribute__((always_inline)) {
+        accn = Mfma32<T>::mfma(bq[0][kk], __builtin_bit_cast(v8, fr[kk]), kk == 0 ? zero16 : accn);
+    };
+
+    // one pipeline step: chain of the next 32-key block (fr -> accn) inside the epilogue of the current one (accc, first key k0); the
+    // fragments of the block after the next one (ring buffer LB, block LKB) follow each MFMA into its registers - unconditionally: where
+    // that block does not exist (end of the stream) the reads return whatever the buffer holds and the chain on them is never used
+    auto step = [&](f16v& accn, const f16v& accc, int k0, auto s_tag, auto mask_tag, auto lb_tag, auto lkb_tag, auto&& hook) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        uint32_t xp[8];
+        const int kv = k0 + l31;   // this lane's key
+        // (MASK) bit c of vism <=> the row with c_k = c sees this lane's key: [mask_a, mask_w) and [mask_b, 32)
+        uint32_t vism = 0xFFFFFFFFu;
+        if (MASK) {
+            vism = vis_bits(k0);
+            asm volatile("" : "+v"(vism));
+        }
+        // -- first half: rounding chain of the 16 logits (four per half-group), one MFMA per half-group
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < MfmaSched<C::KK>::count(qd); ++c) {
+                const int kk = MfmaSched<C::KK>::first(qd) + c;
+                mfma_step(accn, kk);
+                if (qd != 0) load_frag1(fr[kk], lb_tag, lkb_tag, kk);   // (half-group 0: after the hook - the hand-over is there)
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = qd * 4 + j;
+                v[j] = accc[k];
+                if (MASK) {
+                    const int ck = (k & 3) + 8 * (k >> 2);
+                    const int sel = __builtin_amdgcn_sbfe((int)vism, ck, 1);   // all ones: visible
+                    const int vb = (__builtin_bit_cast(int, v[j]) & sel) | (~sel & (int)0xFF800000);   // -inf survives the chain
+                    v[j] = __builtin_bit_cast(float, vb);
+                }
+            }
+            quad_round<T, FAST>(v[0], v[1], v[2], v[3], xp[2 * qd], xp[2 * qd + 1], a.c, a.rcp);
+            if (qd == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                hook();
+#pragma unroll
+                for (int c = 0; c < MfmaSched<C::KK>::count(0); ++c) load_frag1(fr[MfmaSched<C::KK>::first(0) + c], lb_tag, lkb_tag, MfmaSched<C::KK>::first(0) + c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // -- the block's largest logit of this lane (16 rows of one key): reference check, and the bound u for ctx keys
+        const uint32_t pm = pk_max8(xp);
+        const float xmax = fmaxf(pair_lo<T>(pm), pair_hi<T>(pm));
+        {   // (ctx keys are never masked.)  No branch: both halves hold the group's maximum after the swap and store it to the same place;
+            // lanes whose key is not a ctx key store into the spare 64 bytes behind the array
+            const auto sw = __builtin_amdgcn_permlane32_swap(pm, pm, false, false);   // the other 16 rows of the group: lane ^ 32
+            uint32_t both;
+            asm("v_pk_max_f16 %0, %1, %2" : "=v"(both) : "v"(sw[0]), "v"(sw[1]));
+            const uint32_t hi = both >> 16;
+            uint32_t u16;
+            asm("v_max_f16 %0, %1, %2" : "=v"(u16) : "v"(both), "v"(hi));
+            const int j = kv - a.sink;
+            const uint32_t off = ((uint32_t)j < (uint32_t)a.m) ? (uint32_t)(((j >> 5) * a.n_groups) * 64 + (j & 31) * 2) : u_spare;
+            asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
+        }
+        // a logit more than SAFE above the lane's smallest reference (or a NaN): this kernel does not move references inside the pipeline -
+        // the call falls back to the row-per-lane kernels (fallback word = this call's id; everything downstream looks at it)
+        viol |= !(__builtin_fmaf(xmax, L2E, nm_max) <= SAFE_L2);
+        // -- second half: exponentials against the row references, accumulated into the lane-partial row sums
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < MfmaSched<C::KK>::count(4 + qd); ++c) {
+                const int kk = MfmaSched<C::KK>::first(4 + qd) + c;
+                mfma_step(accn, kk);
+                load_frag1(fr[kk], lb_tag, lkb_tag, kk);
+            }
+            float e[4];
+            quad_exp4<T>(xp[2 * qd], xp[2 * qd + 1], L2E, nm[4 * qd], nm[4 * qd + 1], nm[4 * qd + 2], nm[4 * qd + 3], e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float nl;   // (one instruction per statement, outputs not tied: see pass B's running maxima)
+                asm("v_add_f32 %0, %1, %2" : "=v"(nl) : "v"(lsum[4 * qd + j]), "v"(e[j]));
+                lsum[4 * qd + j] = nl;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // first block of an item (ring buffer B of its first tile): its fragments, its chain (nothing to overlap it with), block 1 behind it
+    auto chain0 = [&](auto b_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) load_frag1(fr[kk], b_tag, I0{}, kk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+            mfma_step(acc[0], kk);
+            load_frag1(fr[kk], b_tag, I1{}, kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // rounding chain of the 16 logits in `av` (masked) -> packed pairs
+    auto round16 = [&](const f16v& av, uint32_t vism, uint32_t (&xq)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int kx = qd * 4 + jj;
+                const int ck = (kx & 3) + 8 * (kx >> 2);
+                const int sel = __builtin_amdgcn_sbfe((int)vism, ck, 1);
+                v[jj] = __builtin_bit_cast(float, (__builtin_bit_cast(int, av[kx]) & sel) | (~sel & (int)0xFF800000));
+            }
+            quad_round<T, FAST>(v[0], v[1], v[2], v[3], xq[2 * qd], xq[2 * qd + 1], a.c, a.rcp);
+        }
+    };
+    // references of a new item: the lane's logits of its first block (acc[0], just computed by chain0); hidden (-inf) logits give reference 0,
+    // a NaN logit a NaN addend (the sum becomes NaN as the reference's softmax row does)
+    auto init_refs = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (MFMA result -> assembly block: wait states the compiler does not count)
+        uint32_t xq[8];
+        round16(acc[0], vis_bits(t * SC_TILE), xq);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float xv = (k2 & 1) ? pair_hi<T>(xq[k2 >> 1]) : pair_lo<T>(xq[k2 >> 1]);
+            const float nn = (xv == -INFINITY) ? 0.f : -(xv * L2E);
+            nm[k2] = nn;
+            mx = fmaxf(mx, nn);
+        }
+        nm_max = mx;
+    };
+    bool next_ready = false;
+    // Hand-over in the third step of a tile (B = its buffer).  Every fragment of the tile has been read by now (block 3 in the
+    // second step).  With three buffers the tile two positions ahead goes into the buffer that the PREVIOUS hand-over freed,
+    // so its DMA is issued BEFORE the barrier: a wave that arrives early issues while the others still compute, and after
+    // the barrier only the fragment reads remain.  The counted wait leaves exactly the pieces issued here in flight.
+    auto turnover = [&](auto b_tag) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_tag)::value;
+        constexpr int B1 = (B + 1) % RING, B2 = (B + 2) % RING;
+        int newer = 0;  // tiles staged here that come AFTER the next tile
+        if (staged < sp + 2 && !sq_done) {  // the stream was starved (items of a single tile): the next tile itself is missing
+            sq_stage(B1);
+            ++staged;
+        }
+        if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
+            sq_stage(B2);
+            ++staged;
+            newer = 1;
+        }
+        if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // the next tile (and older pieces) landed
+        else stage_wait();
+        block_barrier();  // ... everybody's part has, and nobody reads tile B any more
+        next_ready = staged >= sp + 2;
+    };
+    auto tile_steps = [&](auto b_tag, auto mask_tag) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_tag)::value;
+        constexpr int B1 = (B + 1) % RING;
+        typedef std::integral_constant<int, B1> IB1;
+        const int k0 = t * SC_TILE;
+        const bool young = wave >= NWAVES / 2;
+        auto nohook = [&]() __attribute__((always_inline)) {};
+        if (young) __builtin_amdgcn_s_setprio(1);
+        step(acc[1], acc[0], k0, I0{}, mask_tag, b_tag, I2{}, nohook);
+        if (young) __builtin_amdgcn_s_setprio(0);
+        step(acc[0], acc[1], k0 + 32, I1{}, mask_tag, b_tag, I3{}, nohook);
+        if (young) __builtin_amdgcn_s_setprio(1);
+        step(acc[1], acc[0], k0 + 64, I2{}, mask_tag, IB1{}, I0{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
+        if (young) __builtin_amdgcn_s_setprio(0);
+        // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
+        step(acc[0], acc[1], k0 + 96, I3{}, mask_tag, IB1{}, I1{}, nohook);
+    };
+    auto tile_dispatch = [&](auto b_tag) __attribute__((always_inline)) {
+        const bool masked = t * SC_TILE + SC_TILE - 1 > wmin;  // some key of the tile is hidden from some row of this wave
+        if (masked) tile_steps(b_tag, std::true_type{});
+        else tile_steps(b_tag, std::false_type{});
+    };
+    // a tile that lies entirely behind the causal limit of every row of this wave: nothing to compute, but the wave still stages its
+    // share of the tiles ahead and takes part in the hand-over (see the row-per-lane kernel).  Every later tile of the item is hidden
+    // too, and the next item starts with its own chain0: no fragments are read here.
+    auto tile_skip = [&]() __attribute__((always_inline)) {
+        const int b1 = (pbuf == RING - 1) ? 0 : pbuf + 1, b2 = (b1 == RING - 1) ? 0 : b1 + 1;
+        int newer = 0;
+        if (staged < sp + 2 && !sq_done) {
+            sq_stage(b1);
+            ++staged;
+        }
+        if (staged < sp + 3 && staged >= sp + 2 && !sq_done) {
+            sq_stage(b2);
+            ++staged;
+            newer = 1;
+        }
+        if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else stage_wait();
+        block_barrier();
+        next_ready = staged >= sp + 2;
+    };
+    (void)diag0;
+
+    chain0(I0{});
+    init_refs();
+    while (true) {
+        if (t >= t_hidden) tile_skip();
+        else if (pbuf == 0) tile_dispatch(I0{});
+        else if (pbuf == 1) tile_dispatch(I1{});
+        else tile_dispatch(I2{});
+        pbuf = (pbuf == RING - 1) ? 0 : pbuf + 1;
+        ++sp;
+        ++t;
+        if (t < cur.t_hi) continue;
+
+        // ---- item finished: partial statistics of this key slice: the 16 lane-partial sums of each half become 16 row sums (lane k of
+        // the half keeps row (k & 3) + 8 (k >> 2) + 4 half), stored as (reference, sum relative to fl(reference * log2e)) ----
+        {
+            float myM = 0.f, myL = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                // the 32 lanes of the half hold (reference, sum) pairs of row k: common reference = the largest one (smallest addend)
+                float nmin = nm[k];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) nmin = fminf(nmin, __shfl_xor(nmin, o, 64));
+                float sm = lsum[k] * __builtin_amdgcn_exp2f(nmin - nm[k]);
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                if (l31 == k) { myM = nmin; myL = sm; }
+            }
+            {   // the reference itself: ref = half(-nm / log2e) exactly (fl(ref * log2e) / log2e is ref (1 +- 2^-23), the next 16-bit value
+                // is 2^-11 away); the stored pair is (reference, sum relative to fl(reference * log2e)) like the row-per-lane kernel's
+                const T rh = (T)(-myM * RL2E);
+                myM = (float)rh;
+            }
+            const int row = cur.rt * PA_ROWS + wave * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * half;
+            if (l31 < 16 && row < R) {
+                float2* dst = a.stats + ((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + row;
+                const float2 val = make_float2(myM, myL);
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+                if (cur.k != u_end) {   // this block walked the unit to its end: neutral statistics in the slots beyond its own partial
+                    const float2 neutral = make_float2(-INFINITY, 0.f);
+                    const int64_t slot_stride = (int64_t)a.n_kv_heads * a.stats_stride;
+                    float2* dn = dst;
+                    for (int sl = cur.z + 1; sl < a.max_seg; ++sl) {
+                        dn += slot_stride;
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dn), "v"(neutral) : "memory");
+                    }
+                }
+            }
+        }
+        if (cur.k != u_end && threadIdx.x == 0) {
+            int* dst = a.unit_nseg + cur.k;
+            const int val = cur.z + 1;
+            asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+        }
+        if (!valid(nxt)) break;
+        // ---- switch to the next item: its query rows landed before the last hand-over; its first tile is in buffer pbuf ----
+        cur = nxt;
+        read_q(bq);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[0][kk]));
+        if (pbuf == 0) chain0(I0{});
+        else if (pbuf == 1) chain0(I1{});
+        else chain0(I2{});
+        nxt = item_from(cur.k + 1);
+        t = cur.t_lo;
+        if (valid(nxt)) stage_q(nxt);
+        if (sq_in_next) {  // the cursor was already inside the item that is now current
+            sq_in_next = false;
+            if (sq_done && valid(nxt)) {
+                sq_done = false;
+                sq_in_next = true;
+                sq_t = nxt.t_lo;
+            }
+        }
+        start_item();
+        init_refs();
+    }
+    if (__builtin_amdgcn_ballot_w64(viol) != 0 && lane == 0) *a.fallback = a.call_id;   // (every writer of this call writes the same word)
+}
+
+// ---- merged statistics, group bounds (round 5) ----------------------------------------------------------------------------------------
+// One block per (256-row tile, KV head), one thread per row: n_r = -(m_r + log l_r) from the unit's partial statistics (the merge of the
+// column-maximum pass: same expression), -inf for the padding rows of the last tile; (max, min) of n over each 32-row group, (NaN, NaN)
+// for a group with a NaN row.  Block 0 resets the candidate counter.
+__global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
+    if (*a.fallback == a.call_id) return;   // (the call is redone by the row-per-lane kernels)
+    const int unit = blockIdx.x;
+    const int rt = a.dh.div(unit), h = unit - rt * a.n_kv_heads;
+    const int R = a.G * a.q_len;
+    const int r = rt * PA_ROWS + (int)threadIdx.x;
+    float n = -INFINITY;
+    bool bad = false;
+    if (r < R) {
+        const int nseg = a.unit_nseg[unit];
+        const float2 v = merge_row_stats(a.stats, (int64_t)a.n_kv_heads * a.stats_stride, (int64_t)h * a.stats_stride + r, nseg);
+        n = -(v.x + v.y);
+        bad = !(n == n);
+    }
+    a.nrow[((int64_t)h * a.n_groups) * 32 + r] = n;
+    float mx = (r < R) ? n : -INFINITY, mn = (r < R) ? n : INFINITY;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    const uint64_t bal = __ballot(bad);
+    const int l = threadIdx.x & 63;
+    const bool gbad = ((l < 32) ? (uint32_t)bal : (uint32_t)(bal >> 32)) != 0;
+    if ((l & 31) == 0) {
+        const int grp = rt * (PA_ROWS / 32) + (int)(threadIdx.x >> 5);
+        const float qnan = __builtin_nanf("");
+        const bool any = rt * PA_ROWS + (int)(threadIdx.x & ~31u) < R;
+        a.gbound[(int64_t)h * a.n_groups + grp] = gbad ? make_float2(qnan, qnan) : (any ? make_float2(mx, mn) : make_float2(-INFINITY, -INFINITY));
+    }
+    if (unit == 0 && threadIdx.x == 0) *a.counter = 0;
+}
+
+// ---- candidate pairs of pass B, compacted (round 5) -----------------------------------------------------------------------------------
+// One block per (KV head, 32-key block).  Its [n_groups][32] slab of u is contiguous (28 KiB at the headline shape): every thread reads 8
+// keys of one group per pass, all passes in flight at once.  LB_j = max_g (u_gj + nmin_g); group g is a candidate of the block iff
+// u_gj + nmax_g >= LB_j for some key j of the block (the fp32 addition pass B applies to a logit and its row's statistic: monotone in
+// both arguments, so the test is exact; NaN bounds keep the pair).  The candidates go into ONE list (entries), those of a block contiguous.
+// A head with a row of NaN statistics is poisoned as the reference's amax over rows poisons it: the block writes the NaN code itself.
+constexpr int BD2_THREADS = 256;
+constexpr int BD2_MAXPASS = 8;   // groups per block <= 64 * 8 (host checks)
+template <typename T>
+__global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a) {
+    if (*a.fallback == a.call_id) return;
+    const int kb = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int oct = tid & 3, grow = tid >> 2;   // 8 keys [8 oct, 8 oct + 8) of group (pass * 64 + grow)
+    __shared__ float s_part[64][33];
+    __shared__ float s_lb8[8][32];
+    __shared__ float s_lb[32];
+    __shared__ uint32_t s_list[64 * BD2_MAXPASS];
+    __shared__ int s_n, s_base, s_poison;
+    if (tid == 0) { s_n = 0; s_poison = 0; }
+    const int ng = a.n_groups;
+    const int npass = (ng + 63) / 64;
+    const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 32);
+    const float2* gb = a.gbound + (int64_t)h * ng;
+    uint4 uu[BD2_MAXPASS];
+    float2 bb[BD2_MAXPASS];
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        const int g = min(p * 64 + grow, ng - 1);
+        if (p < npass) { uu[p] = ub[g * 4 + oct]; bb[p] = gb[g]; }
+    }
+    constexpr int DT = std::is_same<T, __bf16>::value ? KVZ_BF16 : KVZ_F16;
+    auto key = [&](const uint4& v, int i) __attribute__((always_inline)) -> float {
+        const uint32_t w = (i < 2) ? v.x : (i < 4) ? v.y : (i < 6) ? v.z : v.w;
+        return half_bits_to_float((i & 1) ? (w >> 16) : (w & 0xFFFFu), DT);
+    };
+    float lb[8];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb[i] = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        if (p < npass && p * 64 + grow < ng) {
+            bad |= !(bb[p].x == bb[p].x);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lb[i] = fmaxf(lb[i], key(uu[p], i) + bb[p].y);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_part[grow][oct * 8 + i] = lb[i];
+    if (bad) s_poison = 1;
+    __syncthreads();
+    {
+        const int j = tid & 31, part = tid >> 5;
+        float v = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v = fmaxf(v, s_part[part * 8 + q][j]);
+        s_lb8[part][j] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v = fmaxf(v, s_lb8[q][tid]);
+        s_lb[tid] = v;
+    }
+    __syncthreads();
+    if (s_poison) {
+        if (tid < 32 && kb * 32 + tid < a.m) atomicMin(a.log_out + (int64_t)h * a.log_head_stride + kb * 32 + tid, 0u);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb[i] = s_lb[oct * 8 + i];
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        if (p < npass) {   // (uniform: every lane of a quad of threads takes part in the shuffles)
+            const int g = p * 64 + grow;
+            bool c = false;
+            if (g < ng) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ub1 = key(uu[p], i) + bb[p].x;
+                    c |= (kb * 32 + oct * 8 + i < a.m) && (!(ub1 < lb[i]) || a.all_pairs);
+                }
+            }
+            int ci = c ? 1 : 0;
+            ci |= __shfl_xor(ci, 1, 64);
+            ci |= __shfl_xor(ci, 2, 64);
+            if (ci && oct == 0 && g < ng) s_list[atomicAdd(&s_n, 1)] = (uint32_t)g | ((uint32_t)kb << 11) | ((uint32_t)h << 25);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) s_base = (int)atomicAdd(a.counter, (uint32_t)s_n);
+    __syncthreads();
+    for (int i = tid; i < s_n; i += BD2_THREADS) a.entries[s_base + i] = s_list[i];
+}
+
+// ---- pass B over the candidate pairs only (round 5) ---------------------------------------------------------------------------------
+// No stationary tile, no LDS, no barrier: the list of candidate (32-row group, 32-key block) pairs is cut into equal shares, one per
+// wave; a wave keeps the 32 keys of the current key block in registers (B operand: one KEY per lane, as in the key-per-lane pass A),
+// reads the 32 query rows of a pair straight from memory as the A operand (the rows of the next pair are in flight while this one is
+// computed), and holds ONE running maximum per lane; when the key block changes (or the share ends) the two halves of the wave are
+// merged and the 32 maxima go out with the same atomic minimum on the log-score patterns that merges the row slices of the dense pass.
+constexpr int SB_WAVES = 4;
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(ScoreArgs a) {
+    static_assert(std::is_same<T, _Float16>::value, "fp16 only (quad_round)");
+    if (*a.fallback == a.call_id) return;
+    typedef ScoreCfg<D> C;
+    typedef typename Mfma32<T>::v8 v8;
+    constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a pair, swizzled like a key tile
+    constexpr int PB_BYTES = QG_BYTES + 256;         // + their 32 statistics n_r (written twice: one 64-lane dword DMA)
+    __shared__ __attribute__((aligned(16))) char lds[SB_WAVES * 2 * PB_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int R = a.G * a.q_len;
+    const int total = (int)__builtin_amdgcn_readfirstlane((int)*a.counter);
+    const int W = gridDim.x * SB_WAVES, w = blockIdx.x * SB_WAVES + wave;
+    const int per = (total + W - 1) / W;
+    const int lo = w * per, hi = min(total, lo + per);
+    if (lo >= hi) return;
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    char* const wl = lds + wave * 2 * PB_BYTES;
+    const uint32_t wl0 = lds_addr(wl);
+    FragAddr<D> fa0;
+    fa0.init(wl, l31, half);
+    const uint32_t nb0 = wl0 + (uint32_t)QG_BYTES + (uint32_t)(4 * half) * 4u;   // + 32 qd: the statistics of accumulators 4 qd .. 4 qd + 3
+
+    // rows and statistics of pair e -> LDS buffer b of this wave (9 DMA instructions, nothing through registers)
+    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+    const int lrow = lane / C::CPR, pch = lane % C::CPR;
+    const int64_t hs = a.q_head_stride * 2;
+    auto stage = [&](int b, uint32_t e) __attribute__((always_inline)) {
+        const int g = (int)(e & 2047u), h = (int)(e >> 25);
+        const char* qh = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * hs;
+        const uint32_t buf = wl0 + (uint32_t)(b * PB_BYTES);
+        const int rc0 = min(g * 32, R - 1);
+        const int g0 = a.dq.div(rc0), qi0 = rc0 - g0 * a.q_len;   // (wave-uniform; q_len >= 32: at most two query heads per group)
+        const uint32_t base = (uint32_t)(g0 * (int)hs + qi0 * C::ROW_BYTES);
+        const uint32_t wrapd = (uint32_t)((int)hs - a.q_len * C::ROW_BYTES);
+        const int nfirst = a.q_len - qi0, tail = R - 1 - rc0;
+#pragma unroll
+        for (int i = 0; i < 32 / ROWS_PER_INSTR; ++i) {
+            const int row = i * ROWS_PER_INSTR + lrow;
+            const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+            const int rowc = min(row, tail);
+            const uint32_t voff = base + (uint32_t)(rowc * C::ROW_BYTES + chunk * 16) + (rowc >= nfirst ? wrapd : 0u);
+            lds_dma16a(qh, voff, buf + (uint32_t)(i * 1024));
+        }
+        {
+            const char* np = reinterpret_cast<const char*>(a.nrow + ((int64_t)h * a.n_groups + g) * 32);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(buf + (uint32_t)QG_BYTES);
+            const uint64_t bs = (uint64_t)(uintptr_t)np;
+            const uint64_t bss = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bs >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bs);
+            const uint32_t voff = (uint32_t)(l31 * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(bss), "s"(la) : "memory");
+        }
+    };
+    constexpr int STAGE_OPS = 32 / ROWS_PER_INSTR + 1;
+
+    u32x4 bk[C::KK];
+    uint32_t cur = 0xFFFFFFFFu;   // (h, kb) of the keys in bk
+    float best = -INFINITY;
+    auto flush = [&]() __attribute__((always_inline)) {
+        const int kb = (int)(cur & 0x3FFFu), h = (int)(cur >> 14);
+        const uint32_t bb = __builtin_bit_cast(uint32_t, best);
+        const auto sw = __builtin_amdgcn_permlane32_swap(bb, bb, false, false);
+        const float b = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+        const int j = kb * 32 + l31;
+        if (half == 0 && j < a.m) {
+            const uint32_t enc = (b >= 0.f) ? 1u : __builtin_bit_cast(uint32_t, b);   // (the encoding of the dense pass; NaN cannot come here)
+            atomicMin(a.log_out + (int64_t)h * a.log_head_stride + j, enc);
+        }
+    };
+    auto keys_for = [&](uint32_t e) __attribute__((always_inline)) {
+        const uint32_t hk = e >> 11;
+        if (hk != cur) {
+            if (cur != 0xFFFFFFFFu) flush();
+            cur = hk;
+            best = -INFINITY;
+            const int kb = (int)(hk & 0x3FFFu), h = (int)(hk >> 14);
+            const int j = min(kb * 32 + l31, a.m - 1);
+            const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + j) * D) * 2 + half * 16;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) bk[kk] = *reinterpret_cast<const u32x4*>(kp + kk * 32);
+        }
+    };
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f4v* lds_f4_t;
+    auto compute = [&](auto b_tag) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_tag)::value;
+        u32x4 fq[C::KK];
+        frag_load<D>(fq, fa0, B * PB_BYTES);
+        f4v nn[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) nn[qd] = *(lds_f4_t)(uintptr_t)(nb0 + (uint32_t)(B * PB_BYTES + 32 * qd));
+        f16v acc = zero16;
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fq[kk]), __builtin_bit_cast(v8, bk[kk]), acc);
+        // the rounding chain is an assembly block: the compiler does not count the wait states between the last MFMA of the chain and the
+        // first read of its result (18 for a 16-pass MFMA) - the first quad read stale accumulators without them
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            uint32_t xa, xb;
+            quad_round<T, FAST>(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3], xa, xb, a.c, a.rcp);
+            // accumulators 4 qd .. 4 qd + 3 are rows 8 qd + 4 half + (0..3)
+            const float t0 = pair_lo<T>(xa) + nn[qd].x, t1 = pair_hi<T>(xa) + nn[qd].y, t2 = pair_lo<T>(xb) + nn[qd].z, t3 = pair_hi<T>(xb) + nn[qd].w;
+            best = fmaxf(fmaxf(best, fmaxf(t0, t1)), fmaxf(t2, t3));
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    // the share in batches of 64 pairs: one entry per lane, read with v_readlane (a load the compiler sees inside the loop would make it
+    // wait for everything in flight, the staged rows of the next pair included)
+    for (int b0 = lo; b0 < hi; b0 += 64) {
+        const int nb = min(64, hi - b0);
+        const uint32_t ev = a.entries[b0 + min(lane, nb - 1)];
+        auto entry = [&](int i) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ev, i); };
+        stage(0, entry(0));
+        for (int i = 0; i < nb; i += 2) {
+            const bool has1 = i + 1 < nb;
+            if (has1) stage(1, entry(i + 1));
+            if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
+            else stage_wait();
+            keys_for(entry(i));
+            compute(I0{});
+            if (!has1) break;
+            const bool has2 = i + 2 < nb;
+            if (has2) stage(0, entry(i + 2));
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
+            else stage_wait();
+            keys_for(entry(i + 1));
+            compute(I1{});
+        }
+    }
+    flush();
+}
+
 template <typename T>
 __global__ void score_finalize_kernel(const float* __restrict__ colpart, int splits, int Hkv, int m, T* __restrict__ out,
                                       int64_t out_head_stride) {
@@ -1503,6 +2393,54 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     a.unit_rows = PA_ROWS;
     a.max_seg = plan.max_seg;
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
+    const int ctiles = (a.m + PB_COLS - 1) / PB_COLS;
+    // exact pruning of pass B (round 5; knob score_prune: 0 = two full passes; 1 = key-per-lane pass A, every block of pass B (checks);
+    // 3 = candidate pairs only; 4 = every pair through the sparse kernel (checks)).  fp16, deferred-log path.
+    int prune = 0;
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (a.unit_nseg && a.n_groups <= 64 * BD2_MAXPASS && a.nkb < 16384 && Hkv < 128 && a.q_len >= 32) prune = tunable(TUNE_SCORE_PRUNE);
+        if (prune >= 3 && !a.log_out) prune = 1;   // (the sparse pass merges through the log buffer)
+    }
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (prune) {
+            {
+                ProfScope ps("score_rowstat", stream);
+                hipLaunchKernelGGL((score_rowstatT2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
+                KVZ_CHECK_LAUNCH("score_rowstatT2_kernel");
+            }
+            if (prune >= 3) {
+                a.all_pairs = (prune == 4);
+                {
+                    ProfScope ps("score_bounds", stream);
+                    hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_merge_kernel");
+                    hipLaunchKernelGGL((score_bounds2_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_bounds2_kernel");
+                }
+                {
+                    ProfScope ps("score_colmax", stream);
+                    hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST>), dim3(2 * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_colmax_sparse_kernel");
+                }
+                // the fallback: both row-per-lane passes, which return at once unless the key-per-lane pass flagged this call (a logit
+                // outside its safe range: it does not move references inside its pipeline)
+                ProfScope ps("score_fallback", stream);
+                hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST, true>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
+                KVZ_CHECK_LAUNCH("score_rowstat2_kernel (fallback)");
+                hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST, true>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+                KVZ_CHECK_LAUNCH("score_colmax3_kernel (fallback)");
+                return KVZ_OK;
+            }
+            {
+                ProfScope ps("score_colmax", stream);
+                hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+            }
+            KVZ_CHECK_LAUNCH("score_colmax3_kernel");
+        }
+    }
+    if (prune) {
+        // (both passes launched above)
+    } else {
     if (a.unit_nseg) {  // (null: the row statistics came out of the scoring forward's attention kernel - kvz_flash_fwd_window)
         ProfScope ps("score_rowstat", stream);
         hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
@@ -1510,12 +2448,12 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     } else {
         a.max_seg = 1;
     }
-    const int ctiles = (a.m + PB_COLS - 1) / PB_COLS;
     {
         ProfScope ps("score_colmax", stream);
         hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
     }
     KVZ_CHECK_LAUNCH("score_colmax3_kernel");
+    }
     if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,
                        a.row_splits, Hkv, a.m, reinterpret_cast<T*>(a.out), a.out_head_stride);
@@ -1547,9 +2485,20 @@ static inline size_t score_nseg_bytes(int Hkv, int G, int q_len) {
     return align256((size_t)((G * q_len + PA_ROWS - 1) / PA_ROWS) * Hkv * sizeof(int));
 }
 
+// pruning of pass B: 32-row groups (whole row tiles of the key-per-lane pass) and the buffers of that path
+static inline int score_n_groups(int G, int q_len) { return (G * q_len + PA_ROWS - 1) / PA_ROWS * PA_WAVES; }
+static inline size_t score_colu_bytes(int Hkv, int G, int q_len, int m) { return align256((size_t)Hkv * score_n_groups(G, q_len) * ((m + 31) / 32) * 32 * sizeof(uint16_t) + 64); }
+static inline size_t score_gbound_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * sizeof(float2)); }
+static inline size_t score_nrow_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * 32 * sizeof(float)); }
+static inline size_t score_entries_bytes(int Hkv, int G, int q_len, int m) {
+    return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 4) * sizeof(uint32_t));   // ([0]: counter, [1]: fallback word, entries from [4])
+}
+
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0 || sink < 0) return 0;
-    return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len);
+    return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len) +
+           score_colu_bytes(Hkv, G, q_len, m) + score_gbound_bytes(Hkv, G, q_len) + score_nrow_bytes(Hkv, G, q_len) +
+           score_entries_bytes(Hkv, G, q_len, m);
 }
 
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -1650,6 +2599,21 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.stats_stride = score_stats_stride(G, q_len);
     a.colpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + score_stats_bytes(Hkv, G, q_len, m, sink));
     a.unit_nseg = reinterpret_cast<int*>(reinterpret_cast<char*>(a.colpart) + score_colpart_bytes(Hkv, G, q_len, m));
+    a.colu = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.unit_nseg) + score_nseg_bytes(Hkv, G, q_len));
+    a.gbound = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.colu) + score_colu_bytes(Hkv, G, q_len, m));
+    a.nrow = reinterpret_cast<float*>(reinterpret_cast<char*>(a.gbound) + score_gbound_bytes(Hkv, G, q_len));
+    a.counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.nrow) + score_nrow_bytes(Hkv, G, q_len));
+    a.fallback = a.counter + 1;
+    a.entries = a.counter + 4;
+    a.n_groups = score_n_groups(G, q_len);
+    a.all_pairs = 0;
+    {
+        static std::atomic<uint32_t> next_call{1};
+        uint32_t id = next_call.fetch_add(1, std::memory_order_relaxed);
+        if (id == 0) id = next_call.fetch_add(1, std::memory_order_relaxed);
+        a.call_id = id;
+    }
+    a.nkb = (m + 31) / 32;
     if (merged_stats) {  // pass B only: merged (m_r, l'_r) per row [Hkv, merged_stride], no partials, no workspace
         KVZ_REQUIRE(log_out, KVZ_EINVAL, "kvz_score_from_stats: the log buffer is the only output of this path");
         KVZ_REQUIRE(merged_stride >= (int64_t)G * q_len && (reinterpret_cast<uintptr_t>(merged_stats) & 7u) == 0, KVZ_EINVAL,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""PROTOTYPE ONLY - needs tools/proto/score_prune_proto.patch applied to kvzip_amd/csrc (git apply) and the library rebuilt.
+"""Round-5 pruning path (knob score_prune, off by default): checks and times of its variants against the product path.
 Exact pruning of pass B (knob score_prune) through the deferred-log entry points: results and times of the variants.
 0 = two full passes (product), 1 = key-per-lane pass A + full pass B, 2 = + bounds + pruned dense pass B, 3 = + compacted candidate list +
 queue-style sparse pass B.  1, 2 and 3 must agree bit for bit."""
@@ -14,7 +14,8 @@ def main():
     variants = [int(x) for x in os.environ.get("PRUNE_VARIANTS", "0,1,2,3").split(",")]
     shapes = [(4, 7, 2000, 128, 32, 2026, 60000, "gauss"), (4, 7, 2000, 128, 32, 2026, 60000, "copy"), (4, 7, 2000, 128, 32, 2013, 0, "gauss"),
               (2, 4, 777, 128, 4, 790, 1000, "gauss"), (8, 4, 2000, 128, 32, 2026, 3000, "gauss"), (1, 1, 33, 128, 0, 40, 5, "gauss"),
-              (2, 2, 300, 64, 16, 310, 100, "gauss"), (4, 7, 2000, 128, 32, 2026, 60000, "nan"), (4, 7, 2000, 128, 32, 2026, 60000, "const")]
+              (2, 2, 300, 64, 16, 310, 100, "gauss"), (4, 7, 2000, 128, 32, 2026, 60000, "nan"), (4, 7, 2000, 128, 32, 2026, 60000, "const"),
+              (4, 7, 2000, 128, 32, 2026, 60000, "spike"), (4, 7, 2000, 128, 32, 2026, 60000, "neg")]
     st = torch.cuda.current_stream().cuda_stream
     for (Hkv, G, m, D, sink, q_len, s0, kind) in shapes:
         N = s0 + m + 1000
@@ -28,6 +29,10 @@ def main():
             q[:, :, :m] = (q[:, :, :m] * 0.5 + kk * 1.5).half()
         if kind == "nan":
             q[0, 3, 77, 5] = float("nan")      # poisons KV head 0 only
+        if kind == "spike":                    # a few keys with logits far above everything before them: the fallback must take over
+            k[0, 1, start + 700] *= 40.0; k[0, 2, klen - 100] *= 60.0
+        if kind == "neg":                      # all logits very negative except late ones
+            k[0, :, :sink + N] = -k[0, :, :1].abs() * 0 + k[0, :, :sink + N]; q[:] = q.abs(); k[0, :, : start + m] = -k[0, :, : start + m].abs() * 3.0
         if kind == "const":
             q[:] = 0.25; k[:] = 0.5            # every logit equal: every pair is a candidate
         need = lib.kvz_score_workspace_bytes(Hkv, G, q_len, m, sink)
