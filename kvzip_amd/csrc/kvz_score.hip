@@ -1583,13 +1583,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     // smallest reference flags the whole call for the fallback (the row-per-lane kernels), see the end of the kernel.
     constexpr float RL2E = 0.69314718055994530942f;
     float lsum[16], nm[16];
-    float nm_max;   // max_k nm[k] = -(smallest reference) * log2e: x * log2e + nm_max <= SAFE * log2e keeps every exponential below 2^(SAFE log2e)
-    constexpr float SAFE_L2 = 40.f * L2E;     // e^40 x 4 058 keys: far inside fp32; a logit that far above a row's first one is rare
-    bool viol = false;   // (per lane, sticky) some logit was out of the safe range
+    bool viol = false;       // (per lane, sticky) some logit was out of the safe range
     int wmin, t_hidden;   // keys <= wmin are visible to every row of the wave; t_hidden: first tile that no row of this wave sees
     int mask_a0, mask_w, mask_qiw;   // causal mask of the wave's group (see step)
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
     uint32_t u_spare;                // byte offset (from urow) of the spare row behind the array
+    bool tile_ctx = true;            // the current tile holds ctx keys (wave-uniform)
     auto start_item = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) lsum[k] = 0.f;   // (nm, nm_max: init_refs, behind the item's first chain)
@@ -1654,10 +1653,14 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
                 const int k = qd * 4 + j;
                 v[j] = accc[k];
                 if (MASK) {
-                    const int ck = (k & 3) + 8 * (k >> 2);
-                    const int sel = __builtin_amdgcn_sbfe((int)vism, ck, 1);   // all ones: visible
-                    const int vb = (__builtin_bit_cast(int, v[j]) & sel) | (~sel & (int)0xFF800000);   // -inf survives the chain
-                    v[j] = __builtin_bit_cast(float, vb);
+                    constexpr int ck = 0;   // (placeholder: the bit index is passed as an immediate below)
+                    (void)ck;
+                    int sel;
+                    float vo;
+                    const float ninf = -INFINITY;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(vism), "n"((qd * 4 + j) % 4 + 8 * ((qd * 4 + j) / 4)));   // all ones: visible
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(vo) : "v"(sel), "v"(v[j]), "s"(ninf));                              // -inf survives the chain
+                    v[j] = vo;
                 }
             }
             quad_round<T, FAST>(v[0], v[1], v[2], v[3], xp[2 * qd], xp[2 * qd + 1], a.c, a.rcp);
@@ -1670,10 +1673,10 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         }
         __builtin_amdgcn_sched_barrier(0);
         // -- the block's largest logit of this lane (16 rows of one key): reference check, and the bound u for ctx keys
-        const uint32_t pm = pk_max8(xp);
-        const float xmax = fmaxf(pair_lo<T>(pm), pair_hi<T>(pm));
-        {   // (ctx keys are never masked.)  No branch: both halves hold the group's maximum after the swap and store it to the same place;
+        if (tile_ctx) {   // (wave-uniform: the tile holds ctx keys; nothing but temporaries behind this branch)
+            // (ctx keys are never masked.)  Both halves hold the group's maximum after the swap and store it to the same place;
             // lanes whose key is not a ctx key store into the spare 64 bytes behind the array
+            const uint32_t pm = pk_max8(xp);
             const auto sw = __builtin_amdgcn_permlane32_swap(pm, pm, false, false);   // the other 16 rows of the group: lane ^ 32
             uint32_t both;
             asm("v_pk_max_f16 %0, %1, %2" : "=v"(both) : "v"(sw[0]), "v"(sw[1]));
@@ -1684,9 +1687,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             const uint32_t off = ((uint32_t)j < (uint32_t)a.m) ? (uint32_t)(((j >> 5) * a.n_groups) * 64 + (j & 31) * 2) : u_spare;
             asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
         }
-        // a logit more than SAFE above the lane's smallest reference (or a NaN): this kernel does not move references inside the pipeline -
-        // the call falls back to the row-per-lane kernels (fallback word = this call's id; everything downstream looks at it)
-        viol |= !(__builtin_fmaf(xmax, L2E, nm_max) <= SAFE_L2);
         // -- second half: exponentials against the row references, accumulated into the lane-partial row sums
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
@@ -1742,15 +1742,11 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (MFMA result -> assembly block: wait states the compiler does not count)
         uint32_t xq[8];
         round16(acc[0], vis_bits(t * SC_TILE), xq);
-        float mx = -INFINITY;
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const float xv = (k2 & 1) ? pair_hi<T>(xq[k2 >> 1]) : pair_lo<T>(xq[k2 >> 1]);
-            const float nn = (xv == -INFINITY) ? 0.f : -(xv * L2E);
-            nm[k2] = nn;
-            mx = fmaxf(mx, nn);
+            nm[k2] = (xv == -INFINITY) ? 0.f : -(xv * L2E);
         }
-        nm_max = mx;
     };
     bool next_ready = false;
     // Hand-over in the third step of a tile (B = its buffer).  Every fragment of the tile has been read by now (block 3 in the
@@ -1780,6 +1776,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         constexpr int B1 = (B + 1) % RING;
         typedef std::integral_constant<int, B1> IB1;
         const int k0 = t * SC_TILE;
+        tile_ctx = k0 < a.sink + a.m && k0 + SC_TILE > a.sink;
         const bool young = wave >= NWAVES / 2;
         auto nohook = [&]() __attribute__((always_inline)) {};
         if (young) __builtin_amdgcn_s_setprio(1);
@@ -1833,17 +1830,43 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
 
         // ---- item finished: partial statistics of this key slice: the 16 lane-partial sums of each half become 16 row sums (lane k of
         // the half keeps row (k & 3) + 8 (k >> 2) + 4 half), stored as (reference, sum relative to fl(reference * log2e)) ----
+        // this kernel does not move references inside the pipeline: a logit ~88 above its row's reference makes the row's sum inf (or NaN),
+        // and a sum that is not finite sends the call to the row-per-lane kernels (which also give NaN inputs their NaN scores)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) viol |= !(lsum[k] < INFINITY);
         {
             float myM = 0.f, myL = 0.f;
+            auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
+            };
+            typedef std::integral_constant<int, 0x128> ROR8;   // row_ror:8
+            typedef std::integral_constant<int, 0x124> ROR4;   // row_ror:4
+            typedef std::integral_constant<int, 0x4E> QP2;     // quad_perm:[2,3,0,1]
+            typedef std::integral_constant<int, 0xB1> QP1;     // quad_perm:[1,0,3,2]
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                // the 32 lanes of the half hold (reference, sum) pairs of row k: common reference = the largest one (smallest addend)
+                // the 32 lanes of the half hold (reference, sum) pairs of row k: common reference = the largest one (smallest addend);
+                // all-reduce over the half: four DPP steps inside the rows of 16 lanes, then the other row of the half (v_permlane16_swap)
                 float nmin = nm[k];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) nmin = fminf(nmin, __shfl_xor(nmin, o, 64));
+                nmin = fminf(nmin, dpp(nmin, ROR8{}));
+                nmin = fminf(nmin, dpp(nmin, ROR4{}));
+                nmin = fminf(nmin, dpp(nmin, QP2{}));
+                nmin = fminf(nmin, dpp(nmin, QP1{}));
+                {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, nmin);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+                    nmin = fminf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+                }
                 float sm = lsum[k] * __builtin_amdgcn_exp2f(nmin - nm[k]);
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                sm += dpp(sm, ROR8{});
+                sm += dpp(sm, ROR4{});
+                sm += dpp(sm, QP2{});
+                sm += dpp(sm, QP1{});
+                {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, sm);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+                    sm = __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+                }
                 if (l31 == k) { myM = nmin; myL = sm; }
             }
             {   // the reference itself: ref = half(-nm / log2e) exactly (fl(ref * log2e) / log2e is ref (1 +- 2^-23), the next 16-bit value
