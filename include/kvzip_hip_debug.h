@@ -20,8 +20,11 @@ int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* u
 /* test hook, host only: n / d and n % d as the kernels compute them (multiply-shift by a launch-invariant divisor). */
 int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 
-/* test / tuning hook: set a tuning knob of the library ("attn_items", "flash_min_rows", "flash2_min_blocks"; value <= 0 restores
- * the default) and return its previous value (< 0: unknown name).  Process-wide, not thread-safe: for tests and probes. */
+/* test / tuning hook: set a tuning knob of the library ("attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "flash2_split",
+ * "sel_blocks", "emit_blocks", "score_prune"; value <= 0 restores the default) and return its previous value (< 0: unknown name).
+ * "score_prune" (default 0 = off; fp16, deferred-log entry points): 3 = the exact-pruning variant of the scoring call (key-per-lane row
+ * statistics, candidate pairs, sparse column maxima, fallback to the default kernels; kvz_score.hip), 1 / 4 = its check variants.
+ * Process-wide, not thread-safe: for tests and probes. */
 int kvz_debug_set_tunable(const char* name, int value);
 
 #ifdef __cplusplus
