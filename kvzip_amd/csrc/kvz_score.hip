@@ -65,10 +65,9 @@ struct ScoreArgs {
     float* nrow;         // [Hkv, 32 n_groups]  n_r per query row (-inf for the padding rows of the last group)
     uint32_t* entries;   // compacted candidate pairs: g | kb << 11 | h << 25, the pairs of one (h, kb) contiguous
     uint32_t* counter;   // [1] number of entries (zeroed by score_merge_kernel, filled by score_bounds2_kernel)
+    uint32_t* redo;      // [PLAN_MAX_BLOCKS] per block of the key-per-lane pass: items to be redone by its slow loop (self-clearing)
     int n_groups, nkb;
     int all_pairs;       // (debug knob: every pair is a candidate)
-    uint32_t* fallback;  // [1] id of the last call whose key-per-lane pass A met a logit outside its safe range (ids only grow: never reset)
-    uint32_t call_id;    // this call's id (host counter, > 0)
 };
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
@@ -437,11 +436,8 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
     return true;
 }
 
-template <typename T, int D, bool FAST, bool FB = false>   // FB: the fallback launch behind the key-per-lane pass - runs only if that pass flagged this call
+template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstat2_kernel(ScoreArgs a, PaPlan plan) {
-    if constexpr (FB) {
-        if (*a.fallback != a.call_id) return;
-    }
     constexpr int NWAVES = PA_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
@@ -959,11 +955,8 @@ __device__ static inline float2 merge_row_stats(const float2* __restrict__ stats
     const float delta = __builtin_fmaf(M, L2E, -ML2);
     return make_float2(M, logf(Lp) - delta * 0.69314718055994530942f);
 }
-template <typename T, int D, bool FAST, bool FB = false>   // (FB: the fallback launch, see score_rowstat2_kernel)
+template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(ScoreArgs a) {
-    if constexpr (FB) {
-        if (*a.fallback != a.call_id) return;
-    }
     constexpr int NWAVES = PB_WAVES;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
@@ -1378,6 +1371,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     constexpr int QG_BYTES = 32 * C::ROW_BYTES;  // one row group of one wave
     constexpr int RING = 3;  // key-tile buffers: tile p of the block's stream lives in buffer p % 3 (160 KiB of LDS at D = 128)
     __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
+    // (no LDS left for a flag word: the block's "redo" mask - items whose sums left the fp32 range, bit = ordinal of the item in the block -
+    // lives in the workspace; the block clears it when it has read it.  A stale mask only costs a slow pass over the named items.)
+    uint32_t* const redo_word = a.redo + blockIdx.x;
     constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
     constexpr float L2E = 1.44269504088896340736f;
     constexpr int NB = SC_TILE / 32;  // 32-key blocks per tile
@@ -1579,11 +1575,10 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     // per-row state of the lane's 16 rows (accumulator k = row (k & 3) + 8 (k >> 2) + 4 half of the wave's group): lane-partial sum of
     // 2^(x log2e + nm) and the addend nm = -fl(ref * log2e).  The references are LANE-PRIVATE: a lane sees one key per block, its 16 rows take
     // their logits of the item's first block as references (init_refs), so nothing crosses lanes inside the loop; the 32 lanes of a half are
-    // merged like partial statistics when the item ends.  References never move inside the pipeline: a logit more than SAFE above the lane's
-    // smallest reference flags the whole call for the fallback (the row-per-lane kernels), see the end of the kernel.
+    // merged like partial statistics when the item ends.  References never move inside the pipeline; an item whose sums leave the fp32 range
+    // (a logit ~88 above its row's reference) is redone by the slow loop at the end of the kernel.
     constexpr float RL2E = 0.69314718055994530942f;
     float lsum[16], nm[16];
-    bool viol = false;       // (per lane, sticky) some logit was out of the safe range
     int wmin, t_hidden;   // keys <= wmin are visible to every row of the wave; t_hidden: first tile that no row of this wave sees
     int mask_a0, mask_w, mask_qiw;   // causal mask of the wave's group (see step)
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
@@ -1721,7 +1716,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         __builtin_amdgcn_sched_barrier(0);
     };
     // rounding chain of the 16 logits in `av` (masked) -> packed pairs
-    auto round16 = [&](const f16v& av, uint32_t vism, uint32_t (&xq)[8]) __attribute__((always_inline)) {
+    auto round16 = [&](const f16v av, uint32_t vism, uint32_t (&xq)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             float v[4];
@@ -1730,7 +1725,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
                 const int kx = qd * 4 + jj;
                 const int ck = (kx & 3) + 8 * (kx >> 2);
                 const int sel = __builtin_amdgcn_sbfe((int)vism, ck, 1);
-                v[jj] = __builtin_bit_cast(float, (__builtin_bit_cast(int, av[kx]) & sel) | (~sel & (int)0xFF800000));
+                const float lg = av[kx];
+                v[jj] = __builtin_bit_cast(float, (__builtin_bit_cast(int, lg) & sel) | (~sel & (int)0xFF800000));
             }
             quad_round<T, FAST>(v[0], v[1], v[2], v[3], xq[2 * qd], xq[2 * qd + 1], a.c, a.rcp);
         }
@@ -1816,24 +1812,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     };
     (void)diag0;
 
-    chain0(I0{});
-    init_refs();
-    while (true) {
-        if (t >= t_hidden) tile_skip();
-        else if (pbuf == 0) tile_dispatch(I0{});
-        else if (pbuf == 1) tile_dispatch(I1{});
-        else tile_dispatch(I2{});
-        pbuf = (pbuf == RING - 1) ? 0 : pbuf + 1;
-        ++sp;
-        ++t;
-        if (t < cur.t_hi) continue;
-
-        // ---- item finished: partial statistics of this key slice: the 16 lane-partial sums of each half become 16 row sums (lane k of
-        // the half keeps row (k & 3) + 8 (k >> 2) + 4 half), stored as (reference, sum relative to fl(reference * log2e)) ----
-        // this kernel does not move references inside the pipeline: a logit ~88 above its row's reference makes the row's sum inf (or NaN),
-        // and a sum that is not finite sends the call to the row-per-lane kernels (which also give NaN inputs their NaN scores)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) viol |= !(lsum[k] < INFINITY);
+    // partial statistics of the item's key slice: the 16 lane-partial sums of each half become 16 row sums (lane k of the half keeps row
+    // (k & 3) + 8 (k >> 2) + 4 half), stored as (reference, sum relative to fl(reference * log2e)) like the row-per-lane kernel's
+    auto finish_item = [&]() __attribute__((always_inline)) {
         {
             float myM = 0.f, myL = 0.f;
             auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
@@ -1895,6 +1876,28 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             const int val = cur.z + 1;
             asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(val) : "memory");
         }
+    };
+    chain0(I0{});
+    init_refs();
+    while (true) {
+        if (t >= t_hidden) tile_skip();
+        else if (pbuf == 0) tile_dispatch(I0{});
+        else if (pbuf == 1) tile_dispatch(I1{});
+        else tile_dispatch(I2{});
+        pbuf = (pbuf == RING - 1) ? 0 : pbuf + 1;
+        ++sp;
+        ++t;
+        if (t < cur.t_hi) continue;
+
+        // ---- item finished.  This pipeline never moves a reference: a logit ~88 above its row's reference makes the row's sum inf (NaN
+        // inputs: NaN); such an item is redone at the end of the kernel by a slow loop that updates the references in every block ----
+        {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) bad |= !(lsum[k] < INFINITY);
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(redo_word, 1u << ((cur.k - u_first) & 31));
+        }
+        finish_item();
         if (!valid(nxt)) break;
         // ---- switch to the next item: its query rows landed before the last hand-over; its first tile is in buffer pbuf ----
         cur = nxt;
@@ -1918,7 +1921,69 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         start_item();
         init_refs();
     }
-    if (__builtin_amdgcn_ballot_w64(viol) != 0 && lane == 0) *a.fallback = a.call_id;   // (every writer of this call writes the same word)
+
+    // ---- items whose sums left the fp32 range: once more, one tile at a time, no pipeline, the references updated in every block (every
+    // exponential <= 1: nothing can overflow; NaN inputs end as NaN statistics, as in the reference).  The whole block takes part. ----
+    stage_wait();      // (the flag atomics of this wave are done as well)
+    block_barrier();
+    const uint32_t redo = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicOr(redo_word, 0u));   // (read at the L2, where the atomics ran)
+    if (__builtin_expect(redo != 0, 0)) {
+        block_barrier();   // everybody has read the mask
+        if (threadIdx.x == 0) atomicAnd(redo_word, 0u);
+        constexpr float NM_UNSET = 65504.f * L2E;   // reference -65504: "no logit seen yet"
+        typedef const __attribute__((address_space(3))) u32x4* lp_t;
+        for (int u = u_first;; ++u) {
+            const Item it = item_from(u);
+            if (!valid(it)) break;
+            if (!((redo >> ((u - u_first) & 31)) & 1u)) continue;
+            cur = it;
+            stage_q(cur);
+            stage_wait();
+            block_barrier();
+            read_q(bq);
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[0][kk]));
+            start_item();
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) nm[k2] = NM_UNSET;
+            for (int tt = cur.t_lo; tt < cur.t_hi; ++tt) {
+                stage(0, cur.h, tt);
+                stage_wait();
+                block_barrier();
+                if (tt < t_hidden) {
+#pragma unroll 1
+                    for (int sb = 0; sb < 4; ++sb) {
+                        const uint32_t off = (uint32_t)(sb * 32 * C::ROW_BYTES);
+#pragma unroll
+                        for (int kk = 0; kk < C::KK; ++kk) fr[kk] = *(lp_t)(uintptr_t)(fa0.a[kk] + off);
+#pragma unroll
+                        for (int kk = 0; kk < C::KK; ++kk) mfma_step(acc[1], kk);
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+                        uint32_t xq[8];
+                        round16(acc[1], vis_bits(tt * SC_TILE + sb * 32), xq);
+#pragma unroll
+                        for (int k2 = 0; k2 < 16; ++k2) {
+                            const float xv = (k2 & 1) ? pair_hi<T>(xq[k2 >> 1]) : pair_lo<T>(xq[k2 >> 1]);
+                            float nn = fminf(nm[k2], -(xv * L2E));   // (-inf / NaN logits leave the reference alone)
+                            nn = (nn >= NM_UNSET) ? 0.f : nn;         // (nothing finite seen yet: reference 0)
+                            lsum[k2] *= __builtin_amdgcn_exp2f(nn - nm[k2]);
+                            nm[k2] = nn;
+                        }
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            float e[4];
+                            quad_exp4<T>(xq[2 * qd], xq[2 * qd + 1], L2E, nm[4 * qd], nm[4 * qd + 1], nm[4 * qd + 2], nm[4 * qd + 3], e);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) lsum[4 * qd + jj] += e[jj];
+                        }
+                    }
+                }
+                block_barrier();
+            }
+            finish_item();
+        }
+    }
 }
 
 // ---- merged statistics, group bounds (round 5) ----------------------------------------------------------------------------------------
@@ -1926,7 +1991,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
 // column-maximum pass: same expression), -inf for the padding rows of the last tile; (max, min) of n over each 32-row group, (NaN, NaN)
 // for a group with a NaN row.  Block 0 resets the candidate counter.
 __global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
-    if (*a.fallback == a.call_id) return;   // (the call is redone by the row-per-lane kernels)
     const int unit = blockIdx.x;
     const int rt = a.dh.div(unit), h = unit - rt * a.n_kv_heads;
     const int R = a.G * a.q_len;
@@ -1968,7 +2032,6 @@ constexpr int BD2_THREADS = 256;
 constexpr int BD2_MAXPASS = 8;   // groups per block <= 64 * 8 (host checks)
 template <typename T>
 __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a) {
-    if (*a.fallback == a.call_id) return;
     const int kb = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x;
     const int oct = tid & 3, grow = tid >> 2;   // 8 keys [8 oct, 8 oct + 8) of group (pass * 64 + grow)
@@ -2065,7 +2128,6 @@ constexpr int SB_WAVES = 4;
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(ScoreArgs a) {
     static_assert(std::is_same<T, _Float16>::value, "fp16 only (quad_round)");
-    if (*a.fallback == a.call_id) return;
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a pair, swizzled like a key tile
@@ -2445,13 +2507,6 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
                     hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST>), dim3(2 * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
                     KVZ_CHECK_LAUNCH("score_colmax_sparse_kernel");
                 }
-                // the fallback: both row-per-lane passes, which return at once unless the key-per-lane pass flagged this call (a logit
-                // outside its safe range: it does not move references inside its pipeline)
-                ProfScope ps("score_fallback", stream);
-                hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST, true>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
-                KVZ_CHECK_LAUNCH("score_rowstat2_kernel (fallback)");
-                hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST, true>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
-                KVZ_CHECK_LAUNCH("score_colmax3_kernel (fallback)");
                 return KVZ_OK;
             }
             {
@@ -2514,7 +2569,7 @@ static inline size_t score_colu_bytes(int Hkv, int G, int q_len, int m) { return
 static inline size_t score_gbound_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * sizeof(float2)); }
 static inline size_t score_nrow_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * 32 * sizeof(float)); }
 static inline size_t score_entries_bytes(int Hkv, int G, int q_len, int m) {
-    return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 4) * sizeof(uint32_t));   // ([0]: counter, [1]: fallback word, entries from [4])
+    return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 4 + PLAN_MAX_BLOCKS) * sizeof(uint32_t));   // ([0]: the counter, [4..): redo words, then the entries)
 }
 
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
@@ -2626,16 +2681,10 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.gbound = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.colu) + score_colu_bytes(Hkv, G, q_len, m));
     a.nrow = reinterpret_cast<float*>(reinterpret_cast<char*>(a.gbound) + score_gbound_bytes(Hkv, G, q_len));
     a.counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.nrow) + score_nrow_bytes(Hkv, G, q_len));
-    a.fallback = a.counter + 1;
-    a.entries = a.counter + 4;
+    a.redo = a.counter + 4;
+    a.entries = a.redo + PLAN_MAX_BLOCKS;
     a.n_groups = score_n_groups(G, q_len);
     a.all_pairs = 0;
-    {
-        static std::atomic<uint32_t> next_call{1};
-        uint32_t id = next_call.fetch_add(1, std::memory_order_relaxed);
-        if (id == 0) id = next_call.fetch_add(1, std::memory_order_relaxed);
-        a.call_id = id;
-    }
     a.nkb = (m + 31) / 32;
     if (merged_stats) {  // pass B only: merged (m_r, l'_r) per row [Hkv, merged_stride], no partials, no workspace
         KVZ_REQUIRE(log_out, KVZ_EINVAL, "kvz_score_from_stats: the log buffer is the only output of this path");

@@ -1,10 +1,10 @@
 """The exact-pruning variant of the scoring call (round 5, knob ``score_prune``, off by default): a key-per-lane pass A that also writes
 per-group maxima, merged statistics + group bounds, a compacted list of candidate (32-row group, 32-key block) pairs, a sparse pass B over
-those pairs, and a fallback to the product kernels when a logit leaves the key-per-lane pass's safe range.
+those pairs.
 
 What is asserted: against the CPU oracle the same fixed bounds as the product path (``conftest.SCORE_BOUNDS``); the sparse pass B returns
 THE SAME BITS as the full pass B on the same statistics (knob 1 vs 3) and as the sparse pass over every pair (knob 4) - the bounds are
-exact; NaN inputs poison exactly the heads the product path poisons; out-of-range logits end in the product path's own bits."""
+exact; NaN inputs poison exactly the heads the product path poisons; logits beyond the reach of the fixed references are redone in-kernel."""
 import pytest
 import torch
 
@@ -93,21 +93,25 @@ def test_pruned_scoring_call_propagates_nan_like_the_product_path():
     check_score_parity("prune/nan/clean heads", got[[0, 3]], want[[0, 3]])
 
 
-def test_logits_outside_the_safe_range_end_in_the_product_path():
+def test_logits_outside_the_range_of_the_fixed_references_are_redone():
     """the key-per-lane pass keeps the reference of a row where its first key block put it; a later logit ~88 above it makes the row's sum
-    non-finite, the call is flagged and the row-per-lane kernels redo it: the product path's own bits."""
+    non-finite, and the kernel redoes such an item at its end with references that follow the logits: same bounds against the oracle, and
+    the sparse pass still returns the bits of the full pass B on those statistics."""
     H, Hkv, D, sink, N, start, m, q_len = 8, 4, 128, 32, 1500, 32 + 300, 600, 610
     q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=9)
     k[0, 1, start + 400] *= 40.0
     k[0, 2, -100] *= 60.0
+    k[0, 3, 5] *= 50.0
+    want = orc.get_score(q, k, sink, start, start + m)[0]
+    assert not want.isnan().any()
     qd, kd = q.to(DEV), k.to(DEV)
-    ref, got = _score_log(qd, kd, sink, start, start + m, 0), _score_log(qd, kd, sink, start, start + m, 3)
-    assert not ref.isnan().any()
-    assert torch.equal(ref, got)
-    # ... and the next call with ordinary inputs is on the pruned path again and right
+    got1, got3 = _score_log(qd, kd, sink, start, start + m, 1), _score_log(qd, kd, sink, start, start + m, 3)
+    check_score_parity("prune/spikes", got3, want)
+    assert _same_bits(got3, got1)
+    # ... and the next call with ordinary inputs is right as well (the per-block redo masks clear themselves)
     q2, k2 = _inputs(H, Hkv, D, sink, N, q_len, seed=10)
-    want = orc.get_score(q2, k2, sink, start, start + m)[0]
-    check_score_parity("prune/after a fallback", _score_log(q2.to(DEV), k2.to(DEV), sink, start, start + m, 3), want)
+    want2 = orc.get_score(q2, k2, sink, start, start + m)[0]
+    check_score_parity("prune/after a redo", _score_log(q2.to(DEV), k2.to(DEV), sink, start, start + m, 3), want2)
 
 
 @pytest.mark.parametrize("dtype,q_len", [(torch.bfloat16, 610), (torch.float16, 20)])
