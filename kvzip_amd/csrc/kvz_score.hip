@@ -63,8 +63,8 @@ struct ScoreArgs {
     uint16_t* colu;      // [Hkv, nkb, n_groups, 32] (+ 64 spare bytes)  16-bit patterns of u_gj = max over the 32 rows of group g of the logit x_rj
     float2* gbound;      // [Hkv, n_groups]     (max, min) over the rows of group g of  n_r = -(m_r + log l_r);  (NaN, NaN): a row with NaN statistics
     float* nrow;         // [Hkv, 32 n_groups]  n_r per query row (-inf for the padding rows of the last group)
-    uint32_t* entries;   // compacted candidate pairs: g | kb << 11 | h << 25, the pairs of one (h, kb) contiguous
-    uint32_t* counter;   // [1] number of entries (zeroed by score_merge_kernel, filled by score_bounds2_kernel)
+    uint32_t* entries;   // [Hkv, nkb * n_groups] compacted candidate pairs per KV head: g | kb << 11 | h << 25, the pairs of one (h, kb) contiguous
+    uint32_t* counter;   // [Hkv] number of entries per head (zeroed by score_merge_kernel, filled by score_bounds2_kernel)
     uint32_t* redo;      // [PLAN_MAX_BLOCKS] per block of the key-per-lane pass: items to be redone by its slow loop (self-clearing)
     int n_groups, nkb;
     int all_pairs;       // (debug knob: every pair is a candidate)
@@ -1372,8 +1372,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     constexpr int RING = 3;  // key-tile buffers: tile p of the block's stream lives in buffer p % 3 (160 KiB of LDS at D = 128)
     __shared__ __attribute__((aligned(16))) char lds[RING * C::TILE_BYTES + NWAVES * PA_RG * QG_BYTES];
     // (no LDS left for a flag word: the block's "redo" mask - items whose sums left the fp32 range, bit = ordinal of the item in the block -
-    // lives in the workspace; the block clears it when it has read it.  A stale mask only costs a slow pass over the named items.)
+    // lives in the workspace.  The block clears it here, long before its first item ends; the hand-over barrier of the prologue orders the
+    // clear before every wave's flag atomics.)
     uint32_t* const redo_word = a.redo + blockIdx.x;
+    if (threadIdx.x == 0) {
+        atomicAnd(redo_word, 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     constexpr int PIECES = C::TILE_BYTES / 1024 / NWAVES;  // LDS-DMA instructions per wave and tile
     constexpr float L2E = 1.44269504088896340736f;
     constexpr int NB = SC_TILE / 32;  // 32-key blocks per tile
@@ -1928,8 +1933,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     block_barrier();
     const uint32_t redo = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicOr(redo_word, 0u));   // (read at the L2, where the atomics ran)
     if (__builtin_expect(redo != 0, 0)) {
-        block_barrier();   // everybody has read the mask
-        if (threadIdx.x == 0) atomicAnd(redo_word, 0u);
         constexpr float NM_UNSET = 65504.f * L2E;   // reference -65504: "no logit seen yet"
         typedef const __attribute__((address_space(3))) u32x4* lp_t;
         for (int u = u_first;; ++u) {
@@ -2019,7 +2022,7 @@ __global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
         const bool any = rt * PA_ROWS + (int)(threadIdx.x & ~31u) < R;
         a.gbound[(int64_t)h * a.n_groups + grp] = gbad ? make_float2(qnan, qnan) : (any ? make_float2(mx, mn) : make_float2(-INFINITY, -INFINITY));
     }
-    if (unit == 0 && threadIdx.x == 0) *a.counter = 0;
+    if (unit == 0 && (int)threadIdx.x < a.n_kv_heads) a.counter[threadIdx.x] = 0;
 }
 
 // ---- candidate pairs of pass B, compacted (round 5) -----------------------------------------------------------------------------------
@@ -2113,9 +2116,10 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
         }
     }
     __syncthreads();
-    if (tid == 0) s_base = (int)atomicAdd(a.counter, (uint32_t)s_n);
+    if (tid == 0) s_base = (int)atomicAdd(a.counter + h, (uint32_t)s_n);
     __syncthreads();
-    for (int i = tid; i < s_n; i += BD2_THREADS) a.entries[s_base + i] = s_list[i];
+    uint32_t* const eh = a.entries + (int64_t)h * a.nkb * a.n_groups;
+    for (int i = tid; i < s_n; i += BD2_THREADS) eh[s_base + i] = s_list[i];
 }
 
 // ---- pass B over the candidate pairs only (round 5) ---------------------------------------------------------------------------------
@@ -2137,11 +2141,22 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int R = a.G * a.q_len;
-    const int total = (int)__builtin_amdgcn_readfirstlane((int)*a.counter);
-    const int W = gridDim.x * SB_WAVES, w = blockIdx.x * SB_WAVES + wave;
+    // the heads' lists, one after the other, cut into equal shares; blocks are dispatched round-robin over the 8 XCDs: the blocks of one XCD
+    // take one contiguous eighth of the pairs (a head's query rows and keys stay in that XCD's L2)
+    const uint32_t cnt_l = (lane < a.n_kv_heads) ? a.counter[lane] : 0u;   // (Hkv < 128: lanes 0..63 hold heads 0..63, the second word below)
+    const uint32_t cnt_h = (lane + 64 < a.n_kv_heads) ? a.counter[lane + 64] : 0u;
+    auto head_count = [&](int hh) __attribute__((always_inline)) -> int {
+        return hh < 64 ? __builtin_amdgcn_readlane((int)cnt_l, hh) : __builtin_amdgcn_readlane((int)cnt_h, hh - 64);
+    };
+    int total = 0;
+    for (int hh = 0; hh < a.n_kv_heads; ++hh) total += head_count(hh);
+    const int nb8 = (int)gridDim.x >> 3;
+    const int lb = (nb8 > 0 && (gridDim.x & 7u) == 0) ? (int)(blockIdx.x & 7u) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int W = gridDim.x * SB_WAVES, w = lb * SB_WAVES + wave;
     const int per = (total + W - 1) / W;
     const int lo = w * per, hi = min(total, lo + per);
     if (lo >= hi) return;
+    const int64_t head_cap = (int64_t)a.nkb * a.n_groups;
     const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     char* const wl = lds + wave * 2 * PB_BYTES;
     const uint32_t wl0 = lds_addr(wl);
@@ -2239,9 +2254,12 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
     typedef std::integral_constant<int, 1> I1;
     // the share in batches of 64 pairs: one entry per lane, read with v_readlane (a load the compiler sees inside the loop would make it
     // wait for everything in flight, the staged rows of the next pair included)
-    for (int b0 = lo; b0 < hi; b0 += 64) {
-        const int nb = min(64, hi - b0);
-        const uint32_t ev = a.entries[b0 + min(lane, nb - 1)];
+    // (a batch lies inside one head's list)
+    int hcur = 0, hbase = 0;   // head of position b0, global position of its first pair
+    for (int b0 = lo; b0 < hi;) {
+        while (b0 >= hbase + head_count(hcur)) { hbase += head_count(hcur); ++hcur; }
+        const int nb = min(min(64, hi - b0), hbase + head_count(hcur) - b0);
+        const uint32_t ev = a.entries[hcur * head_cap + (b0 - hbase) + min(lane, nb - 1)];
         auto entry = [&](int i) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ev, i); };
         stage(0, entry(0));
         for (int i = 0; i < nb; i += 2) {
@@ -2259,6 +2277,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
             keys_for(entry(i + 1));
             compute(I1{});
         }
+        b0 += nb;
     }
     flush();
 }
@@ -2569,7 +2588,7 @@ static inline size_t score_colu_bytes(int Hkv, int G, int q_len, int m) { return
 static inline size_t score_gbound_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * sizeof(float2)); }
 static inline size_t score_nrow_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * 32 * sizeof(float)); }
 static inline size_t score_entries_bytes(int Hkv, int G, int q_len, int m) {
-    return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 4 + PLAN_MAX_BLOCKS) * sizeof(uint32_t));   // ([0]: the counter, [4..): redo words, then the entries)
+    return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 128 + PLAN_MAX_BLOCKS) * sizeof(uint32_t));   // (per-head counters, redo words, entries)
 }
 
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
@@ -2681,7 +2700,7 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.gbound = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.colu) + score_colu_bytes(Hkv, G, q_len, m));
     a.nrow = reinterpret_cast<float*>(reinterpret_cast<char*>(a.gbound) + score_gbound_bytes(Hkv, G, q_len));
     a.counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.nrow) + score_nrow_bytes(Hkv, G, q_len));
-    a.redo = a.counter + 4;
+    a.redo = a.counter + 128;   // (one counter per KV head: Hkv < 128)
     a.entries = a.redo + PLAN_MAX_BLOCKS;
     a.n_groups = score_n_groups(G, q_len);
     a.all_pairs = 0;

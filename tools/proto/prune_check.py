@@ -62,8 +62,8 @@ def main():
             extra = ""
             if pr == 3:   # the candidate list sits at the end of the workspace: [counter, pad x 3, entries ...]
                 ng = (G * q_len + 255) // 256 * 8; nkb = (m + 31) // 32
-                eb = ((Hkv * nkb * ng + 4 + 256) * 4 + 255) // 256 * 256
-                cnt = int(ws[need - eb:need - eb + 4].view(torch.int32)[0])
+                eb = ((Hkv * nkb * ng + 128 + 256) * 4 + 255) // 256 * 256
+                cnt = int(ws[need - eb:need - eb + 4 * Hkv].view(torch.int32).sum())
                 extra = f"  candidates {cnt} of {Hkv * nkb * ng} ({100.0 * cnt / (Hkv * nkb * ng):.1f} %)"
                 if os.environ.get("PRUNE_DEBUG"):
                     nb = (Hkv * ng * 32 * 4 + 255) // 256 * 256
@@ -94,7 +94,7 @@ def main():
                     extra += f"(key, true row, row % 32, true t, got t, rows whose value was returned) {info}"
                     extra += f"\n    true-row % 32 histogram of the differing keys: {torch.bincount(rows_true[badk] % 32, minlength=32).tolist()}"
                     # which group holds the true maximum of the first bad key, and is it in the list?
-                    ent = ws[need - eb + 16 + 1024:need - eb + 16 + 1024 + 4 * cnt].view(torch.int32).long() & 0xFFFFFFFF
+                    ent = ws[need - eb + 512 + 1024:need - eb + 512 + 1024 + 4 * int(ws[need - eb:need - eb + 4].view(torch.int32)[0])].view(torch.int32).long() & 0xFFFFFFFF
                     jb = int(torch.nonzero(d3 > 1e-3).flatten()[0]) if (d3 > 1e-3).any() else -1
                     if jb >= 0:
                         rstar = int((x[:, sink + jb] - c).argmax()); gstar = rstar // 32
