@@ -60,7 +60,7 @@ struct ScoreArgs {
     uint32_t* log_out;   // non-NULL: pass B merges its row slices by atomic unsigned-min on the bit patterns of the (non-positive)
     int64_t log_head_stride;  // fp32 log-scores into [Hkv, log_head_stride] instead of writing colpart; no finalize launch
     // ---- exact pruning of pass B (round 5: score_rowstatT2_kernel, score_merge_kernel, score_bounds2_kernel, score_colmax_sparse_kernel)
-    uint16_t* colu;      // [Hkv, nkb, n_groups, 32] (+ 64 spare bytes)  16-bit patterns of u_gj = max over the 32 rows of group g of the logit x_rj
+    uint16_t* colu;      // [Hkv, nkb, n_groups, 2, 32] (+ 128 spare bytes)  16-bit patterns of max over the 16 rows of each HALF of group g of the logit x_rj
     float2* gbound;      // [Hkv, n_groups]     (max, min) over the rows of group g of  n_r = -(m_r + log l_r);  (NaN, NaN): a row with NaN statistics
     float* nrow;         // [Hkv, 32 n_groups]  n_r per query row (-inf for the padding rows of the last group)
     uint32_t* entries;   // [Hkv, nkb * n_groups] compacted candidate pairs per KV head: g | kb << 11 | h << 25, the pairs of one (h, kb) contiguous
@@ -1524,9 +1524,19 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     // block n + 1 as soon as the MFMA that consumed them has been issued - the 32 registers are where the 16 per-row sums and addends of
     // this layout live
     typedef const __attribute__((address_space(3))) u32x4* lds_frag_t;
+    // (the ds_read offset field holds 16 bits and the ring spans 96 KiB at D = 128: the third buffer is read through a second set of bases -
+    // without it every fragment read of that buffer costs an address add)
+    constexpr bool FAR_BASE = RING * C::TILE_BYTES > 65536;
+    FragAddr<D> fa_far;
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) {
+        fa_far.a[kk] = fa0.a[kk] + 65536u;
+        if (FAR_BASE) asm volatile("" : "+v"(fa_far.a[kk]));
+    }
     auto load_frag1 = [&](u32x4& dst, auto b_tag, auto kb_tag, int kk) __attribute__((always_inline)) {
         constexpr int off = decltype(b_tag)::value * C::TILE_BYTES + decltype(kb_tag)::value * 32 * C::ROW_BYTES;
-        dst = *(lds_frag_t)(uintptr_t)(fa0.a[kk] + off);
+        if constexpr (FAR_BASE && off >= 65536) dst = *(lds_frag_t)(uintptr_t)(fa_far.a[kk] + (off - 65536));
+        else dst = *(lds_frag_t)(uintptr_t)(fa0.a[kk] + off);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -1587,7 +1597,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     int wmin, t_hidden;   // keys <= wmin are visible to every row of the wave; t_hidden: first tile that no row of this wave sees
     int mask_a0, mask_w, mask_qiw;   // causal mask of the wave's group (see step)
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
-    uint32_t u_spare;                // byte offset (from urow) of the spare row behind the array
+    uint32_t u_spare, u_lane;        // byte offsets from urow: the spare row behind the array; the lane's part of its key's offset
+    int u_c;                         // (lane & 31) - sink: ctx index of the lane's key minus k0
     bool tile_ctx = true;            // the current tile holds ctx keys (wave-uniform)
     auto start_item = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1604,8 +1615,12 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         mask_a0 = -a.sink - a.m - qi0;   // + k0 + (lane & 31) - 4 half -> d - qi0 - 4 half
         mask_w = iw;                     // - 4 half
         mask_qiw = qi0 + iw;
-        urow = a.colu + ((int64_t)cur.h * a.nkb * a.n_groups + (cur.rt * PA_WAVES + wave)) * 32;
-        u_spare = (uint32_t)((((int64_t)a.n_kv_heads - cur.h) * a.nkb * a.n_groups - (cur.rt * PA_WAVES + wave)) * 64) + (uint32_t)(l31 * 2);
+        // u: [Hkv, nkb, n_groups, 2 halves, 32 keys] 16-bit; k0 is a multiple of 32, so with c = (lane & 31) - sink the ctx index k0 + c lies in
+        // key block k0 / 32 + (c >> 5) at position c & 31
+        urow = a.colu + ((int64_t)cur.h * a.nkb * a.n_groups + (cur.rt * PA_WAVES + wave)) * 64;
+        u_spare = (uint32_t)((((int64_t)a.n_kv_heads - cur.h) * a.nkb * a.n_groups - (cur.rt * PA_WAVES + wave)) * 128) + (uint32_t)(lane * 2);
+        u_c = l31 - a.sink;
+        u_lane = (uint32_t)((u_c >> 5) * a.n_groups * 128 + half * 64 + (u_c & 31) * 2);
     };
     start_item();
 
@@ -1674,17 +1689,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         __builtin_amdgcn_sched_barrier(0);
         // -- the block's largest logit of this lane (16 rows of one key): reference check, and the bound u for ctx keys
         if (tile_ctx) {   // (wave-uniform: the tile holds ctx keys; nothing but temporaries behind this branch)
-            // (ctx keys are never masked.)  Both halves hold the group's maximum after the swap and store it to the same place;
-            // lanes whose key is not a ctx key store into the spare 64 bytes behind the array
+            // (ctx keys are never masked.)  Each half stores the maximum of ITS 16 rows (the two are merged by the reader); lanes whose key is
+            // not a ctx key store into the spare bytes behind the array
             const uint32_t pm = pk_max8(xp);
-            const auto sw = __builtin_amdgcn_permlane32_swap(pm, pm, false, false);   // the other 16 rows of the group: lane ^ 32
-            uint32_t both;
-            asm("v_pk_max_f16 %0, %1, %2" : "=v"(both) : "v"(sw[0]), "v"(sw[1]));
-            const uint32_t hi = both >> 16;
+            const uint32_t hi = pm >> 16;
             uint32_t u16;
-            asm("v_max_f16 %0, %1, %2" : "=v"(u16) : "v"(both), "v"(hi));
-            const int j = kv - a.sink;
-            const uint32_t off = ((uint32_t)j < (uint32_t)a.m) ? (uint32_t)(((j >> 5) * a.n_groups) * 64 + (j & 31) * 2) : u_spare;
+            asm("v_max_f16 %0, %1, %2" : "=v"(u16) : "v"(pm), "v"(hi));
+            const uint32_t off = ((uint32_t)(k0 + u_c) < (uint32_t)a.m) ? (uint32_t)((k0 >> 5) * a.n_groups * 128) + u_lane : u_spare;
             asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
         }
         // -- second half: exponentials against the row references, accumulated into the lane-partial row sums
@@ -2046,14 +2057,23 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
     if (tid == 0) { s_n = 0; s_poison = 0; }
     const int ng = a.n_groups;
     const int npass = (ng + 63) / 64;
-    const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 32);
+    const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 64);   // per group: 8 uint4 (two halves of 32 keys)
     const float2* gb = a.gbound + (int64_t)h * ng;
     uint4 uu[BD2_MAXPASS];
     float2 bb[BD2_MAXPASS];
 #pragma unroll
     for (int p = 0; p < BD2_MAXPASS; ++p) {
         const int g = min(p * 64 + grow, ng - 1);
-        if (p < npass) { uu[p] = ub[g * 4 + oct]; bb[p] = gb[g]; }
+        if (p < npass) {
+            const uint4 u0 = ub[g * 8 + oct], u1 = ub[g * 8 + 4 + oct];
+            auto pkmax = [](uint32_t x, uint32_t y) __attribute__((always_inline)) -> uint32_t {
+                uint32_t r;
+                asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+                return r;
+            };
+            uu[p] = make_uint4(pkmax(u0.x, u1.x), pkmax(u0.y, u1.y), pkmax(u0.z, u1.z), pkmax(u0.w, u1.w));
+            bb[p] = gb[g];
+        }
     }
     constexpr int DT = std::is_same<T, __bf16>::value ? KVZ_BF16 : KVZ_F16;
     auto key = [&](const uint4& v, int i) __attribute__((always_inline)) -> float {
@@ -2584,7 +2604,7 @@ static inline size_t score_nseg_bytes(int Hkv, int G, int q_len) {
 
 // pruning of pass B: 32-row groups (whole row tiles of the key-per-lane pass) and the buffers of that path
 static inline int score_n_groups(int G, int q_len) { return (G * q_len + PA_ROWS - 1) / PA_ROWS * PA_WAVES; }
-static inline size_t score_colu_bytes(int Hkv, int G, int q_len, int m) { return align256((size_t)Hkv * score_n_groups(G, q_len) * ((m + 31) / 32) * 32 * sizeof(uint16_t) + 64); }
+static inline size_t score_colu_bytes(int Hkv, int G, int q_len, int m) { return align256((size_t)Hkv * score_n_groups(G, q_len) * ((m + 31) / 32) * 64 * sizeof(uint16_t) + 128); }
 static inline size_t score_gbound_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * sizeof(float2)); }
 static inline size_t score_nrow_bytes(int Hkv, int G, int q_len) { return align256((size_t)Hkv * score_n_groups(G, q_len) * 32 * sizeof(float)); }
 static inline size_t score_entries_bytes(int Hkv, int G, int q_len, int m) {
