@@ -2,6 +2,7 @@
 // C ABI (include/kvzip_hip.h).
 #include "kvz_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -104,6 +105,12 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 //   2 = pass B only over the (32-row group, 32-key block) pairs the bounds of pass A cannot rule out (fp16, deferred-log path).
 static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 0};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
 static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {0}};   // (atomic: a probe may flip a knob while another thread launches)
+// (KVZIP_SCORE_PRUNE in the environment presets the score_prune knob when the library is loaded: A/B runs of whole programs)
+static const int g_tune_env = [] {
+    const char* e = getenv("KVZIP_SCORE_PRUNE");
+    if (e && *e) g_tune[TUNE_SCORE_PRUNE].store(atoi(e), std::memory_order_relaxed);
+    return 0;
+}();
 int tunable(Tunable t) { return g_tune[t].load(std::memory_order_relaxed); }
 int device_cus() {
     static const int n = [] {
