@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
     uint32_t u_spare, u_lane;        // byte offsets from urow: the spare row behind the array; the lane's part of its key's offset
     int u_c;                         // (lane & 31) - sink: ctx index of the lane's key minus k0
-    bool tile_ctx = true;            // the current tile holds ctx keys (wave-uniform)
+    bool tile_ctx = true, tile_ctx_full = false;   // the current tile holds ctx keys / nothing but ctx keys (wave-uniform)
     auto start_item = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) lsum[k] = 0.f;   // (nm, nm_max: init_refs, behind the item's first chain)
@@ -1630,7 +1630,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int h4 = (lane_o >> 5) * 4;
-        const int mask_a = mask_a0 + k0 + (lane_o & 31) - h4, mw = mask_w - h4, mask_b = max(mask_a + mask_qiw, mw);
+        const int mask_a = mask_a0 + k0 + (lane_o & 31) - h4;
+        if (mask_w >= 64) return ones_from(mask_a);   // (wave-uniform: the group does not wrap into the next query head - rows >= d - qi0 see the key)
+        const int mw = mask_w - h4, mask_b = max(mask_a + mask_qiw, mw);
         return (ones_from(mask_a) & ~ones_from(mw)) | ones_from(mask_b);
     };
     f16v acc[2];
@@ -1695,7 +1697,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             const uint32_t hi = pm >> 16;
             uint32_t u16;
             asm("v_max_f16 %0, %1, %2" : "=v"(u16) : "v"(pm), "v"(hi));
-            const uint32_t off = ((uint32_t)(k0 + u_c) < (uint32_t)a.m) ? (uint32_t)((k0 >> 5) * a.n_groups * 128) + u_lane : u_spare;
+            uint32_t off = (uint32_t)((k0 >> 5) * a.n_groups * 128) + u_lane;
+            if (!tile_ctx_full) off = ((uint32_t)(k0 + u_c) < (uint32_t)a.m) ? off : u_spare;   // (wave-uniform: only the tiles at the ends of the ctx range)
             asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
         }
         // -- second half: exponentials against the row references, accumulated into the lane-partial row sums
@@ -1789,6 +1792,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         typedef std::integral_constant<int, B1> IB1;
         const int k0 = t * SC_TILE;
         tile_ctx = k0 < a.sink + a.m && k0 + SC_TILE > a.sink;
+        tile_ctx_full = k0 >= a.sink && k0 + SC_TILE <= a.sink + a.m;
         const bool young = wave >= NWAVES / 2;
         auto nohook = [&]() __attribute__((always_inline)) {};
         if (young) __builtin_amdgcn_s_setprio(1);
