@@ -121,3 +121,17 @@ def test_knob_is_ignored_where_the_path_does_not_apply(dtype, q_len):
     q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=3, dtype=dtype)
     qd, kd = q.to(DEV), k.to(DEV)
     assert torch.equal(_score_log(qd, kd, sink, start, start + m, 0), _score_log(qd, kd, sink, start, start + m, 3))
+
+
+def test_reference_fixtures_end_to_end_with_the_pruning_path_on():
+    """the reference-generated end-to-end fixtures (scores -> threshold -> mask of 64 000 / 512 000 / 128 000 scores, fp16) through the whole
+    cache object with the knob preset by the environment (a fresh process: the knob is read when the library is loaded)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVZIP_SCORE_PRUNE="3")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_e2e_parity.py"), "-x", "-q", "-m", "gpu", "-k", "f16"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-1000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-500:]
