@@ -75,8 +75,9 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group even with one GPU and push the result gather and the max-over-ranks "
                          "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
-    ap.add_argument("--score-streams", type=int, default=2,
-                    help="side streams over which the scoring calls of consecutive layers are issued (1 = caller's stream)")
+    ap.add_argument("--score-streams", type=int, default=0,
+                    help="side streams over which the scoring calls of consecutive layers are issued (0 = the library's choice: three with "
+                         "the pruned fp16 call, two otherwise; 1 = caller's stream)")
     args = ap.parse_args(argv)
     if args.ratio is None:
         args.ratio = 0.6 if args.level == "head" else 0.3
@@ -380,7 +381,7 @@ def _run(args):
         if prev_kv[0] is not None:
             prev_kv[0].close()   # (the previous step's cache: its events go back now, not when the collector gets to it)
         kv = prev_kv[0] = EvictCache(cfg, (sink, sink + N), device=dev, dtype=dtype, verbose=False)
-        kv.n_score_streams = max(1, args.score_streams)
+        kv.n_score_streams = max(0, args.score_streams)
         kv.fuse_update_score = not args.unfused_update  # what kvzip_amd.attn / ModelKVzip.scoring do: update + _get_score = one call
         kv.adopt_dense(store_k, store_v, sink + N)
         if head_level:
@@ -441,7 +442,7 @@ def _run(args):
     timing["on"] = False
     assert len(records) == world and all(r is not None and r["n_kept"] > 0 for r in records)
 
-    prof = {n: prof_read(lib, n) for n in ("score_rowstat", "score_colmax", "select", "select_heads", "compact_gather")}
+    prof = {n: prof_read(lib, n) for n in ("score_rowstat", "score_bounds", "score_colmax", "select", "select_heads", "compact_gather")}
 
     # ---- post-prune decode: append + variable-length attention, q_len = 1 (attention only) ------------------
     lib.kvz_prof_reset()
@@ -597,15 +598,23 @@ def _run(args):
         avg_flops_a, avg_flops_b = flops_lc[0], flops_b[0]   # the bracketed launches are calls of the first chunk (q = m + 13)
         a_tf, a_ms, a_n = stage("score_rowstat", avg_flops_a, 1e12)
         b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
+        # the pruned call (fp16 default, knob score_prune): two small launches between the passes - merged statistics + group bounds,
+        # candidate pairs - and a column-maximum pass that recomputes the candidate pairs only (its flops are NOT the full ctx-column flops)
+        pruned = prof.get("score_bounds", (0.0, 0))[1] > 0
+        m_ms = (prof["score_bounds"][0] / prof["score_bounds"][1]) if pruned else 0.0
         s_gbs, s_ms, s_n = stage("select", 5.0 * L * Hkv * N, 1e9)
-        score_combined_tf = avg_flops_a / ((a_ms + b_ms) / 1e3) / 1e12
+        score_combined_tf = avg_flops_a / ((a_ms + m_ms + b_ms) / 1e3) / 1e12
         step_flops = L * sum(flops_lc)                                                       # SURVEY 8(d) flops of one whole step
         stages.update({
             "score_rowstat": {"bound": "mfma", "achieved": a_tf, "unit": "TFLOP/s", "frac": a_tf / MFMA_PEAK_TFLOPS,
                               "avg_ms": a_ms, "launches": a_n,
                               "note": "pass A alone, credited with ALL of the call's 8(d) flops (the convention of rounds 1-4)"},
-            "score_colmax": {"bound": "mfma", "achieved": b_tf, "unit": "TFLOP/s", "frac": b_tf / MFMA_PEAK_TFLOPS,
-                             "avg_ms": b_ms, "launches": b_n, "note": "pass B alone over its own recomputed ctx-column flops"},
+            "score_colmax": {"bound": "mfma", "achieved": None if pruned else b_tf, "unit": "TFLOP/s", "frac": None if pruned else b_tf / MFMA_PEAK_TFLOPS,
+                             "avg_ms": b_ms, "launches": b_n,
+                             "note": ("sparse pass B: only the candidate (32-row group, 32-key block) pairs are recomputed (exact bounds from pass A)"
+                                      if pruned else "pass B alone over its own recomputed ctx-column flops")},
+            "score_bounds": ({"avg_ms": m_ms, "launches": prof["score_bounds"][1],
+                              "note": "statistics merge + group bounds, candidate pairs (two launches in one bracket)"} if pruned else None),
             "score_combined": {"bound": "mfma", "achieved": score_combined_tf, "unit": "TFLOP/s",
                                "frac": score_combined_tf / MFMA_PEAK_TFLOPS},
             "select": {"bound": "hbm", "achieved": s_gbs, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS, "avg_ms": s_ms,
@@ -613,19 +622,21 @@ def _run(args):
         })
         # Round 5: the headline roofline is the scoring STAGE - both launches of a (layer, chunk) call - not pass A alone
         roofline = {
-            "bound": "mfma", "kernel": "score (rowstat + colmax)", "achieved": score_combined_tf, "peak": MFMA_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": "score (rowstat + bounds + sparse colmax)" if pruned else "score (rowstat + colmax)",
+            "achieved": score_combined_tf, "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": score_combined_tf / MFMA_PEAK_TFLOPS,
-            "avg_ms": a_ms + b_ms, "launches": min(a_n, b_n),
-            "traffic": ((pmc.get("score_rowstat", {}).get("traffic_bytes") or 0) + (pmc.get("score_colmax", {}).get("traffic_bytes") or 0)) or None,
+            "avg_ms": a_ms + m_ms + b_ms, "launches": min(a_n, b_n), "pruned_call": pruned,
+            "traffic": (sum((pmc.get(kn, {}).get("traffic_bytes") or 0) for kn in
+                            (("score_rowstatT2", "score_merge", "score_bounds2", "score_colmax_sparse") if pruned else ("score_rowstat", "score_colmax"))) or None),
             "achieved_step_tflops": step_flops / (elapsed / args.steps) / 1e12,   # per GPU: 8(d) flops of one context's step / ms_per_step
             "peak_random_fp16_operands": MFMA_RANDOM_DATA_TFLOPS,
             "frac_of_peak_random_fp16_operands": score_combined_tf / MFMA_RANDOM_DATA_TFLOPS,
             "note": ("the scoring stage: algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) call (QK^T only, SURVEY §8d) over the "
-                     "time of BOTH launches (pass A rowstat + pass B colmax; per pass: roofline_stages); achieved_step_tflops = the "
+                     "time of ALL launches of the call (pass A rowstat [+ merge / bounds + candidate pairs] + pass B colmax; per launch: roofline_stages); achieved_step_tflops = the "
                      "same flops of a whole step over ms_per_step (side streams, selection and compaction included); kernel durations "
                      f"from hipEvents on the launch stream inside the timed region: the first {n_prof} scoring calls of every step (first "
                      "chunk, q = m + 13) run alone on the caller's stream and are bracketed (the GPU is idle at a step's start: no "
-                     f"pipeline is drained), the others overlap on {max(1, args.score_streams)} side streams; traffic: separate rocprofv3 "
+                     f"pipeline is drained), the others overlap on {len({st_.cuda_stream for st_ in getattr(kv, '_score_side', [])}) or 1} side streams; traffic: separate rocprofv3 "
                      "--pmc passes (profiles/*_pmc_traffic.json); peak_random_fp16_operands: what v_mfma_f32_32x32x16_f16 alone "
                      "sustains on random operands at this part's power limit (1.65 GHz; profiles/r5_scoring_attribution.txt)"),
         }
@@ -634,7 +645,7 @@ def _run(args):
         # --pmc pass, profiles/*_pmc_traffic.json) / 1024 SIMDs / the clock the kernels run at = the time the stage would take if its
         # VALU streams issued back to back with everything else hidden; `frac` = that time / the measured duration.
         sqa, sqb = pmc.get("_sq_counters", {}).get("score_rowstat2", {}), pmc.get("_sq_counters", {}).get("score_colmax3", {})
-        if sqa.get("SQ_ACTIVE_INST_VALU") and sqb.get("SQ_ACTIVE_INST_VALU"):
+        if sqa.get("SQ_ACTIVE_INST_VALU") and sqb.get("SQ_ACTIVE_INST_VALU") and not pruned:   # (counters of the two-pass kernels)
             us = lambda sq: 4.0 * sq["SQ_ACTIVE_INST_VALU"] / 1024 / (CLOCK_UNDER_SCORING_GHZ * 1e3)
             mf = lambda sq: 32.0 * sq.get("SQ_INSTS_MFMA", 0) / 1024 / (CLOCK_UNDER_SCORING_GHZ * 1e3)
             mfp = lambda sq: sq.get("SQ_INSTS_MFMA", 0) / 1024 * (32 * 32 * 16 * 2 * 1024 / (MFMA_RANDOM_DATA_TFLOPS * 1e12)) * 1e6
@@ -652,6 +663,19 @@ def _run(args):
                 "note": "counters from a separate rocprofv3 --pmc pass at this geometry (file read); rounds 1-4 priced this bound at the "
                         "2.35 GHz rocm-smi reports - the kernels run at 1.95 GHz (power limit), where VALU + MFMA time add up to "
                         "~0.95 of the measured duration (profiles/r5_scoring_attribution.txt)"}
+        sqs = pmc.get("_sq_counters", {})
+        if pruned and all(sqs.get(kn, {}).get("SQ_ACTIVE_INST_VALU") for kn in ("score_rowstatT2", "score_colmax_sparse")):
+            us = lambda sq: 4.0 * sq["SQ_ACTIVE_INST_VALU"] / 1024 / (CLOCK_UNDER_SCORING_GHZ * 1e3)
+            mfp = lambda sq: sq.get("SQ_INSTS_MFMA", 0) / 1024 * (32 * 32 * 16 * 2 * 1024 / (MFMA_RANDOM_DATA_TFLOPS * 1e12)) * 1e6
+            ka, kb = sqs["score_rowstatT2"], sqs["score_colmax_sparse"]
+            roofline["valu_issue_bound"] = {
+                "valu_active_us": {"rowstat": us(ka), "colmax_sparse": us(kb)}, "mfma_at_power_limit_us": {"rowstat": mfp(ka), "colmax_sparse": mfp(kb)},
+                "valu_plus_mfma_at_power_limit_us": us(ka) + us(kb) + mfp(ka) + mfp(kb), "measured_us": (a_ms + m_ms + b_ms) * 1e3,
+                "frac_of_valu_plus_mfma_at_power_limit": (us(ka) + us(kb) + mfp(ka) + mfp(kb)) / ((a_ms + m_ms + b_ms) * 1e3),
+                "simds": 1024, "clock_ghz_under_load": CLOCK_UNDER_SCORING_GHZ,
+                "note": "counters of the pruned call's two MFMA kernels from a separate rocprofv3 --pmc pass (file read); time = MFMAs per SIMD x "
+                        "19.7 ns + VALU-active time (profiles/r5_scoring_attribution.txt); the rest of the bracket is the latency of the two small "
+                        "launches between the passes and of the sparse pass's fixed part, which other streams fill in the loop"}
         workload = (f"{args.model} geometry (L{L} H{H} Hkv{Hkv} D{D}), {N}-token synthetic context, sink {sink}, "
                     f"{len(chunks)} scoring chunks of {args.chunk}, ratio {ratio}: score + select + compact; "
                     "one independent context per GPU")
@@ -672,7 +696,7 @@ def _run(args):
                            + (f" ({backend_version()}; process group of {world} rank(s)" + (", forced on one GPU)" if ranks.forced else ")")
                               if ranks.dist is not None else " (no process group: single rank)"),
             "gathered_contexts": len(records),
-            "score_streams": max(1, args.score_streams),
+            "score_streams": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
             "score_streams_distinct": len({st.cuda_stream for st in getattr(kv, "_score_side", [])}) or 1,
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
             "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,

@@ -21,11 +21,13 @@ int kvz_debug_score_plan(int sink, int m, int q_len, int G, int Hkv, uint16_t* u
 int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 
 /* test / tuning hook: set a tuning knob of the library ("attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "flash2_split",
- * "sel_blocks", "emit_blocks", "score_prune"; value <= 0 restores the default) and return its previous value (< 0: unknown name).
- * "score_prune" (default 0 = off; fp16, deferred-log entry points): 3 = the exact-pruning variant of the scoring call (key-per-lane row
- * statistics, candidate pairs, sparse column maxima, fallback to the default kernels; kvz_score.hip), 1 / 4 = its check variants.
- * Process-wide, not thread-safe: for tests and probes. */
+ * "sel_blocks", "emit_blocks", "score_prune"; value <= 0 restores the default - the on / off knobs flash2_xcd, flash2_split and score_prune
+ * take 0 as "off" and negative values as "default") and return its previous value (< 0: unknown name).
+ * "score_prune" (fp16, deferred-log entry points): 3 (default) = key-per-lane row statistics + candidate pairs + sparse column maxima,
+ * 0 = two full passes over Q.K^T, 1 / 4 = check variants (kvz_score.hip); KVZIP_SCORE_PRUNE in the environment presets it.
+ * Process-wide, not thread-safe: for tests and probes.  kvz_debug_get_tunable: the current value. */
 int kvz_debug_set_tunable(const char* name, int value);
+int kvz_debug_get_tunable(const char* name);
 
 #ifdef __cplusplus
 }

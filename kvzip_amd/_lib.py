@@ -47,6 +47,7 @@ SIGNATURES = {
     "kvz_debug_round_chain": (_i, [_vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "kvz_debug_fastdiv": (_i, [_i, _i, _vp, _vp]),
     "kvz_debug_set_tunable": (_i, [C.c_char_p, _i]),
+    "kvz_debug_get_tunable": (_i, [C.c_char_p]),
     "kvz_debug_score_plan": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -101,10 +101,11 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 // sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (default 0 =
 //   one per CU, device_cus(): every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-// score_prune: 0 = two full passes over Q.K^T (default); 1 = key-per-lane pass A (score_rowstatT_kernel), pass B over every block;
-//   2 = pass B only over the (32-row group, 32-key block) pairs the bounds of pass A cannot rule out (fp16, deferred-log path).
-static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 0};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
-static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {0}};   // (atomic: a probe may flip a knob while another thread launches)
+// score_prune (fp16, deferred-log entry points; everything else takes the two full passes whatever the knob says): 3 (default) = key-per-lane
+//   row statistics + candidate pairs + sparse column maxima (kvz_score.hip, round 5); 0 = two full passes over Q.K^T; 1 / 4 = check variants
+//   (key-per-lane statistics with the full column-maximum pass / every pair through the sparse pass).  KVZIP_SCORE_PRUNE presets it.
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 3};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {3}};   // (atomic: a probe may flip a knob while another thread launches)
 // (KVZIP_SCORE_PRUNE in the environment presets the score_prune knob when the library is loaded: A/B runs of whole programs)
 static const int g_tune_env = [] {
     const char* e = getenv("KVZIP_SCORE_PRUNE");
@@ -125,10 +126,20 @@ extern "C" int kvz_debug_set_tunable(const char* name, int value) {
     KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_set_tunable: null name");
     for (int i = 0; i < kvz::TUNE_COUNT; ++i)
         if (strcmp(name, kvz::g_tune_name[i]) == 0) {
-            // (value <= 0 restores the default; the on / off knobs flash2_xcd and flash2_split take 0 as "off" and negative values as "default")
-            return kvz::g_tune[i].exchange((value > 0 || ((i == kvz::TUNE_FLASH2_XCD || i == kvz::TUNE_FLASH2_SPLIT) && value == 0)) ? value : kvz::g_tune_default[i]);
+            // (value <= 0 restores the default; the on / off knobs flash2_xcd, flash2_split and score_prune take 0 as "off" and negative
+            // values as "default")
+            const bool onoff = i == kvz::TUNE_FLASH2_XCD || i == kvz::TUNE_FLASH2_SPLIT || i == kvz::TUNE_SCORE_PRUNE;
+            return kvz::g_tune[i].exchange((value > 0 || (onoff && value == 0)) ? value : kvz::g_tune_default[i]);
         }
     kvz::set_error("kvz_debug_set_tunable: unknown knob '%s'", name);
+    return KVZ_EINVAL;
+}
+
+extern "C" int kvz_debug_get_tunable(const char* name) {
+    KVZ_REQUIRE(name, KVZ_EINVAL, "kvz_debug_get_tunable: null name");
+    for (int i = 0; i < kvz::TUNE_COUNT; ++i)
+        if (strcmp(name, kvz::g_tune_name[i]) == 0) return kvz::tunable((kvz::Tunable)i);
+    kvz::set_error("kvz_debug_get_tunable: unknown knob '%s'", name);
     return KVZ_EINVAL;
 }
 

@@ -9,7 +9,7 @@ Differences that are deliberate (and invisible through the interface):
   * ``_threshold_uniform`` breaks ties towards the lowest index (``torch.topk`` leaves it unspecified);
   * ``_get_score`` is ASYNCHRONOUS with respect to the caller's stream: the scores of a layer are a side product that
     nothing in the forward pass consumes, so the kernels of consecutive layers are issued round-robin on
-    ``n_score_streams`` (default 2) side streams.  The tail of one persistent kernel, the launch gaps and the two tiny
+    ``n_score_streams`` side streams (default: automatic, three with the pruned fp16 call, two otherwise).  The tail of one persistent kernel, the launch gaps and the two tiny
     merge / finalize kernels of a call then overlap with the big kernels of the next ones (+9 % scoring throughput on
     MI355X with two streams; round 5, same boxes: three streams are 3-4.5 % SLOWER than two, four 7 % - rounds 2-3 had measured
     three ahead when a call still had a separate merge launch).  Ordering is kept with events: the side stream waits for the caller's stream (inputs), ``update`` of a layer
@@ -118,7 +118,8 @@ class KVScore:
         self._score_fill: List[int] = []
         self._score_ws: List[Optional[torch.Tensor]] = []
         self._ws_need = {}             # (q_len, m, H) -> workspace bytes
-        self.n_score_streams = 2       # 1 = score on the caller's stream (round 5: two side streams beat three by 3-4.5 % on three boxes, profiles/r5_streams_ab.txt)
+        self.n_score_streams = 0       # 0 = automatic: three side streams where the pruned scoring call runs (fp16: its small kernels fill the gaps
+                                       # of the other streams' big ones, +4 %), two for the two-pass call (profiles/r5_streams_ab.txt); 1 = the caller's stream
         self._score_exclusive = False  # True: the next calls run alone on the caller's stream (clean kernel timings)
         self._score_side: List["torch.cuda.Stream"] = []
         self._async = -1               # handle of the library's asynchronous-scoring context (events per layer)
@@ -131,6 +132,13 @@ class KVScore:
         self.fuse_forward_score = False       # set by the forward pass this package owns (kvzip_amd.attn via ModelKVzip.scoring)
 
     # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
+    def _auto_streams(self, lib, dtype) -> int:
+        """side streams of the scoring calls: ``n_score_streams`` if set, else three where the pruned call (knob ``score_prune``, fp16) runs
+        and two for the two-pass call (bf16, or the knob off)."""
+        if self.n_score_streams:
+            return max(1, int(self.n_score_streams))
+        return 3 if (dtype == torch.float16 and lib.kvz_debug_get_tunable(b"score_prune") >= 3) else 2
+
     @property
     def score(self):
         """Per-layer scores (reference attribute: list of L ``[1, Hkv, n]`` tensors, or whatever was assigned).  Reading it
@@ -272,7 +280,7 @@ class KVScore:
         need = self._ws_need.get((q_len, m, H))
         if need is None:
             need = self._ws_need[(q_len, m, H)] = lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, self.sink)
-        nstreams = 1 if self._score_exclusive else max(1, int(self.n_score_streams))
+        nstreams = 1 if self._score_exclusive else self._auto_streams(lib, query_states.dtype)
         slot = layer_idx % nstreams if nstreams > 1 else 0
         while len(self._score_ws) <= slot:
             self._score_ws.append(None)
@@ -376,7 +384,7 @@ class KVScore:
             self._async = lib.kvz_async_create(self.n_layers)
             if self._async < 0:
                 ops.check(self._async, "kvz_async_create")
-        nstreams = 1 if self._score_exclusive else max(1, int(self.n_score_streams))
+        nstreams = 1 if self._score_exclusive else (max(1, int(self.n_score_streams)) if self.n_score_streams else 2)
         slot = layer_idx % nstreams if nstreams > 1 else 0
         cur = ops.raw_stream(dev.index)
         if nstreams == 1:

@@ -1,4 +1,4 @@
-"""The exact-pruning variant of the scoring call (round 5, knob ``score_prune``, off by default): a key-per-lane pass A that also writes
+"""The exact-pruning variant of the scoring call (round 5, knob ``score_prune``: 3 = the fp16 default, 0 = the two-pass call): a key-per-lane pass A that also writes
 per-group maxima, merged statistics + group bounds, a compacted list of candidate (32-row group, 32-key block) pairs, a sparse pass B over
 those pairs.
 
@@ -35,7 +35,7 @@ def _score_log(q, k, sink, start, end, prune):
         ops.check(lib.kvz_score_finalize_log(log.data_ptr(), log.numel(), out.data_ptr(), ops._dtype_code(q.dtype), st), "kvz_score_finalize_log")
         torch.cuda.synchronize()
     finally:
-        lib.kvz_debug_set_tunable(b"score_prune", 0)
+        lib.kvz_debug_set_tunable(b"score_prune", -1)   # (back to the default)
     return out.cpu()
 
 

@@ -23,14 +23,25 @@ if what == "score":
     q = torch.randn(1, H, q_len, D, generator=g, device=dev).to(dt)
     k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
     start = sink + 60000
+    # the deferred-log entry point (what a scoring pass calls): the pruned call for fp16 by default, the two-pass call with
+    # KVZIP_SCORE_PRUNE=0 in the environment
+    from kvzip_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, sink), dtype=torch.uint8, device=dev)
+    log = torch.empty(Hkv, m, dtype=torch.int32, device=dev)
+    def call():
+        ops.check(lib.kvz_score_log_fill(log.data_ptr(), log.numel(), st), "fill")
+        ops.check(lib.kvz_score_chunk_log(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), klen, sink, start, start + m, q_len, Hkv, H // Hkv, D,
+                                          ops._dtype_code(q.dtype), log.data_ptr(), m, ws.data_ptr(), ws.numel(), st), "score_chunk_log")
     for _ in range(2):
-        ops.score_chunk(q, k, sink, start, start + m)
+        call()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        ops.score_chunk(q, k, sink, start, start + m)
+        call()
     torch.cuda.synchronize()
-    print(f"score_chunk: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
+    print(f"score_chunk_log: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per call")
 elif what == "attn":
     G = H // Hkv
     lens = torch.tensor([39000, 39500, 38800, 39900], dtype=torch.int32, device=dev)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round-5 pruning path (knob score_prune, off by default): checks and times of its variants against the product path.
+"""Round-5 pruned scoring call (knob score_prune: 3 = fp16 default, 0 = two-pass call): checks and times of its variants.
 Exact pruning of pass B (knob score_prune) through the deferred-log entry points: results and times of the variants.
 0 = two full passes (product), 1 = key-per-lane pass A + full pass B, 2 = + bounds + pruned dense pass B, 3 = + compacted candidate list +
 queue-style sparse pass B.  1, 2 and 3 must agree bit for bit."""
@@ -101,7 +101,7 @@ def main():
                         code = gstar | ((jb // 32) << 11) | (0 << 25)
                         extra += f"\n    key {jb}: true max at row {rstar} (group {gstar}), value {float(t_ref[jb]):.4f}, variant 3 {float(out[3][0, jb]):.4f}; pair in the list: {bool((ent == code).any())}"
             print(f"  prune={pr} {json.dumps(t)}{extra}")
-        lib.kvz_debug_set_tunable(b"score_prune", 0)
+        lib.kvz_debug_set_tunable(b"score_prune", -1)
         ref = out[variants[0]]
         msg = []
         for pr in variants[1:]:
