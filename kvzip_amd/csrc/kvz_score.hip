@@ -2289,16 +2289,16 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
         for (int i = 0; i < nb; i += 2) {
             const bool has1 = i + 1 < nb;
             if (has1) stage(1, entry(i + 1));
+            keys_for(entry(i));   // (a key block's loads are issued before the wait for the staged rows: one round trip, not two)
             if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
             else stage_wait();
-            keys_for(entry(i));
             compute(I0{});
             if (!has1) break;
             const bool has2 = i + 2 < nb;
             if (has2) stage(0, entry(i + 2));
+            keys_for(entry(i + 1));
             if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
             else stage_wait();
-            keys_for(entry(i + 1));
             compute(I1{});
         }
         b0 += nb;
