@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KVZ_ABI_VERSION 4
+#define KVZ_ABI_VERSION 5
 
 /* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
 #define KVZ_F16 0

@@ -29,6 +29,12 @@ int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 int kvz_debug_set_tunable(const char* name, int value);
 int kvz_debug_get_tunable(const char* name);
 
+/* measurement hook (round 6): a plain 16-bytes-per-lane copy KERNEL, dst[0 .. nbytes) = src[0 .. nbytes) (both 16-byte aligned, nbytes a
+ * multiple of 16) - the yardstick the micro-architecture guide quotes for achievable HBM bandwidth (read + write), next to the runtime's
+ * own device-to-device copy.  variant 0: ordinary loads / stores, 1: non-temporal (the compaction kernel's kind).  bench.py times both on
+ * the box it runs on and reports the gather against the better one (roofline_stages.compact_gather.frac_of_box_copy_kernel). */
+int kvz_debug_copy_kernel(void* dst, const void* src, size_t nbytes, int variant, kvz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVZIP_HIP_LIB", os.path.join(_HERE, "libkvzip_hip.so"))  # override: A/B builds
 
 KVZ_F16, KVZ_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); mirrors include/kvzip_hip.h (+ the test hooks of include/kvzip_hip_debug.h) one to one
 _vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
@@ -48,6 +48,7 @@ SIGNATURES = {
     "kvz_debug_fastdiv": (_i, [_i, _i, _vp, _vp]),
     "kvz_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "kvz_debug_get_tunable": (_i, [C.c_char_p]),
+    "kvz_debug_copy_kernel": (_i, [_vp, _vp, _sz, _i, _vp]),
     "kvz_debug_score_plan": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "kvz_select_workspace_bytes": (_sz, []),
     "kvz_select_threshold": (_i, [_vp, _i64, _d, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -91,12 +92,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C kvzip_amd/csrc`). There is no CPU fallback for the product path.")
     lib = C.CDLL(LIB_PATH)
+    lib.kvz_abi_version.restype = C.c_int
+    if lib.kvz_abi_version() != ABI_VERSION:   # (first: a stale library must fail with THIS message, not with a missing symbol)
+        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding {ABI_VERSION} - rebuild {LIB_PATH}")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.kvz_abi_version() != ABI_VERSION:
-        raise KvzError(f"ABI version mismatch: library {lib.kvz_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 

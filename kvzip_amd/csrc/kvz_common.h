@@ -68,7 +68,7 @@ static inline FastDiv make_fastdiv(int d) {
     return f;
 }
 
-// ---- tuning knobs with a test hook (kvz_debug_set_tunable; no environment variables inside the library) ----
+// ---- tuning knobs with a test hook (kvz_debug_set_tunable; ONE environment variable, read when the library is loaded: KVZIP_SCORE_PRUNE presets score_prune) ----
 enum Tunable { TUNE_ATTN_ITEMS = 0, TUNE_FLASH_MIN_ROWS = 1, TUNE_FLASH2_MIN_BLOCKS = 2, TUNE_FLASH2_XCD = 3, TUNE_SEL_BLOCKS = 4, TUNE_EMIT_BLOCKS = 5, TUNE_FLASH2_SPLIT = 6, TUNE_SCORE_PRUNE = 7, TUNE_COUNT = 8 };
 int tunable(Tunable t);
 // compute units of the current device (cached hipDeviceAttributeMultiprocessorCount; 256 on MI355X): "one block per CU" launch sizes

@@ -451,3 +451,39 @@ extern "C" int kvz_dense_append(void* k_cache, void* v_cache, int64_t cache_head
     KVZ_CHECK_LAUNCH("dense_append_kernel");
     return KVZ_OK;
 }
+
+
+// ---- measurement hook: a plain 16-bytes-per-lane copy kernel (include/kvzip_hip_debug.h) -----------------------------------------------
+namespace kvz {
+template <bool NT>
+__global__ __launch_bounds__(256) void copy16_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src, size_t n16) {
+    constexpr int U = 4;   // 16-byte moves in flight per lane
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n16; i += stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + (size_t)u * 256 < n16) v[u] = NT ? __builtin_nontemporal_load(src + i + (size_t)u * 256) : src[i + (size_t)u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + (size_t)u * 256 < n16) {
+                if (NT) __builtin_nontemporal_store(v[u], dst + i + (size_t)u * 256);
+                else dst[i + (size_t)u * 256] = v[u];
+            }
+    }
+}
+}  // namespace kvz
+
+extern "C" int kvz_debug_copy_kernel(void* dst, const void* src, size_t nbytes, int variant, kvz_stream_t stream_) {
+    KVZ_REQUIRE(dst && src && aligned16(dst) && aligned16(src) && nbytes % 16 == 0, KVZ_EINVAL, "kvz_debug_copy_kernel: 16-byte aligned buffers and size");
+    if (nbytes == 0) return KVZ_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n16 = nbytes / 16;
+    size_t blocks = (n16 + 1023) / 1024;
+    const size_t cap = (size_t)device_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (variant == 1) hipLaunchKernelGGL((kvz::copy16_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<kvz::u32x4*>(dst), reinterpret_cast<const kvz::u32x4*>(src), n16);
+    else hipLaunchKernelGGL((kvz::copy16_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<kvz::u32x4*>(dst), reinterpret_cast<const kvz::u32x4*>(src), n16);
+    KVZ_CHECK_LAUNCH("copy16_kernel");
+    return KVZ_OK;
+}

@@ -191,6 +191,9 @@ __device__ static inline void stage_tile_linear(char* buf, const char* base, uin
 #ifndef KVZ_PA_FAR_BASE
 #define KVZ_PA_FAR_BASE 1
 #endif
+#ifndef KVZ_T2_BLOCKMASK
+#define KVZ_T2_BLOCKMASK 0
+#endif
 constexpr int PA_WAVES = 8;
 constexpr int PA_RG = 1;                        // 32-row groups per wave
 constexpr int PA_ROWS = PA_WAVES * PA_RG * 32;  // query rows per work item
@@ -1324,6 +1327,23 @@ __device__ static inline void quad_round(float a0, float a1, float a2, float a3,
             "v_cvt_pk_f16_f32 %[xb], %[g2], %[g3]"
             : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3)
             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp));
+    } else if constexpr (std::is_same<T, __bf16>::value && FAST) {
+        // (the first twelve instructions of quad_args' bf16 block: plain fp32 multiplications, see there)
+        float g0, g1, g2, g3;
+        asm("v_cvt_pk_bf16_f32 %[xa], %[a0], %[a1]\n\t"
+            "v_cvt_pk_bf16_f32 %[xb], %[a2], %[a3]\n\t"
+            "v_lshlrev_b32 %[g0], 16, %[xa]\n\t"
+            "v_and_b32 %[g1], 0xffff0000, %[xa]\n\t"
+            "v_lshlrev_b32 %[g2], 16, %[xb]\n\t"
+            "v_and_b32 %[g3], 0xffff0000, %[xb]\n\t"
+            "v_mul_f32 %[g0], %[r], %[g0]\n\t"
+            "v_mul_f32 %[g1], %[r], %[g1]\n\t"
+            "v_mul_f32 %[g2], %[r], %[g2]\n\t"
+            "v_mul_f32 %[g3], %[r], %[g3]\n\t"
+            "v_cvt_pk_bf16_f32 %[xa], %[g0], %[g1]\n\t"
+            "v_cvt_pk_bf16_f32 %[xb], %[g2], %[g3]"
+            : [xa] "=&v"(xa), [xb] "=&v"(xb), [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3)
+            : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [r] "s"(rcp));
     } else {
         const T x0 = round_chain_h<T, FAST>(a0, c, rcp), x1 = round_chain_h<T, FAST>(a1, c, rcp);
         const T x2 = round_chain_h<T, FAST>(a2, c, rcp), x3 = round_chain_h<T, FAST>(a3, c, rcp);
@@ -1353,14 +1373,76 @@ __device__ static inline void quad_exp4(uint32_t xa, uint32_t xb, float L2E, flo
         e[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xb), L2E, n3));
     }
 }
-// maximum of the two 16-bit halves of eight packed registers, as fp32 (NaN propagates: v_pk_maximum3_f16)
-__device__ static inline uint32_t pk_max8(const uint32_t (&xp)[8]) {
+// the same with ONE wave-uniform addend (scalar register) for all four logits (round 6: the key-per-lane pass keeps one reference per wave)
+template <typename T>
+__device__ static inline void quad_exp4s(uint32_t xa, uint32_t xb, float L2E, float n /* wave-uniform */, float (&e)[4]) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        float g0, g1, g2, g3;
+        asm("v_fma_mix_f32 %[g0], %[xa], %[l2e], %[n] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g2], %[xb], %[l2e], %[n] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g1], %[xa], %[l2e], %[n] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[g3], %[xb], %[l2e], %[n] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_exp_f32 %[e0], %[g0]\n\t"
+            "v_exp_f32 %[e2], %[g2]\n\t"
+            "v_exp_f32 %[e1], %[g1]\n\t"
+            "v_exp_f32 %[e3], %[g3]"
+            : [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+            : [xa] "v"(xa), [xb] "v"(xb), [l2e] "v"(L2E), [n] "s"(n));
+    } else {
+        e[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xa), L2E, n));
+        e[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xa), L2E, n));
+        e[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_lo<T>(xb), L2E, n));
+        e[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(pair_hi<T>(xb), L2E, n));
+    }
+}
+// bf16 (round 6): the sixteen logits of a step are unpacked ONCE (shift / mask), the maximum for the bound u and the exponent block both
+// read the fp32 values: four fma (plain fp32: packed fp32 arithmetic issues slower on this part, see quad_args) and four exponentials
+__device__ static inline void quad_exp4f(float x0, float x1, float x2, float x3, float L2E, float n /* wave-uniform */, float (&e)[4]) {
+    float g0, g1, g2, g3;
+    asm("v_fma_f32 %[g0], %[x0], %[l2e], %[n]\n\t"
+        "v_fma_f32 %[g2], %[x2], %[l2e], %[n]\n\t"
+        "v_fma_f32 %[g1], %[x1], %[l2e], %[n]\n\t"
+        "v_fma_f32 %[g3], %[x3], %[l2e], %[n]\n\t"
+        "v_exp_f32 %[e0], %[g0]\n\t"
+        "v_exp_f32 %[e2], %[g2]\n\t"
+        "v_exp_f32 %[e1], %[g1]\n\t"
+        "v_exp_f32 %[e3], %[g3]"
+        : [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+        : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [l2e] "v"(L2E), [n] "s"(n));
+}
+// NaN-propagating maximum of sixteen fp32 values
+__device__ static inline float max16_f32(const float (&x)[16]) {
+    float f;
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(x[0]), "v"(x[1]), "v"(x[2]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[3]), "v"(x[4]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[5]), "v"(x[6]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[7]), "v"(x[8]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[9]), "v"(x[10]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[11]), "v"(x[12]));
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(x[13]), "v"(x[14]));
+    asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(f) : "v"(f), "v"(x[15]));
+    return f;
+}
+// maximum of the sixteen 16-bit values of eight packed registers: its 16-bit pattern in the LOW half of the result (the high half is
+// unspecified).  NaN propagates through the three-operand maxima (v_pk_maximum3_f16 / v_maximum3_f32); the last fp16 step is an IEEE maxNum.
+template <typename T> __device__ static inline uint32_t max16_bits(const uint32_t (&xp)[8]) {
     uint32_t m;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(xp[0]), "v"(xp[1]), "v"(xp[2]));
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[3]), "v"(xp[4]));
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[5]), "v"(xp[6]));
-    asm("v_pk_maximum3_f16 %0, %1, %2, %2" : "=v"(m) : "v"(m), "v"(xp[7]));
-    return m;
+    if constexpr (std::is_same<T, _Float16>::value) {
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(xp[0]), "v"(xp[1]), "v"(xp[2]));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[3]), "v"(xp[4]));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(xp[5]), "v"(xp[6]));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %2" : "=v"(m) : "v"(m), "v"(xp[7]));
+        uint32_t r;
+        asm("v_max_f16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(m));
+        return r;
+    } else {
+        // bf16 has no packed maximum: the sixteen values as fp32 (shift / mask - the exponent block unpacks them the same way), eight
+        // three-operand maxima; the result is one of the inputs, so its low 16 bits are zero and the shift back is exact
+        float xf[16];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { xf[2 * p] = pair_lo<T>(xp[p]); xf[2 * p + 1] = pair_hi<T>(xp[p]); }
+        return __builtin_bit_cast(uint32_t, max16_f32(xf)) >> 16;
+    }
 }
 
 template <typename T, int D, bool FAST>
@@ -1593,8 +1675,10 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     // merged like partial statistics when the item ends.  References never move inside the pipeline; an item whose sums leave the fp32 range
     // (a logit ~88 above its row's reference) is redone by the slow loop at the end of the kernel.
     constexpr float RL2E = 0.69314718055994530942f;
-    float lsum[16], nm[16];
-    int wmin, t_hidden;   // keys <= wmin are visible to every row of the wave; t_hidden: first tile that no row of this wave sees
+    float lsum[16];
+    float refw = 0.f, nmw = 0.f;   // the wave's reference (a 16-bit value, or 0) and the addend -fl(refw * log2e): scalar registers
+    int wmin, wmax, t_hidden;   // keys <= wmin are visible to every row of the wave, keys > wmax to none; t_hidden: first tile that no row of this wave sees
+    int item_qi0, item_iw;      // position of the wave's first row in its query head; rows of the group before the wrap into the next head (64: none)
     int mask_a0, mask_w, mask_qiw;   // causal mask of the wave's group (see step)
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
     uint32_t u_spare, u_lane;        // byte offsets from urow: the spare row behind the array; the lane's part of its key's offset
@@ -1608,10 +1692,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         const int qi0 = a.dq.mod(rc0), n = last - rc0;
         const bool wraps = qi0 + n >= a.q_len;
         wmin = a.sink + a.m + (wraps ? 0 : qi0);
-        t_hidden = max((a.sink + a.m + (wraps ? a.q_len - 1 : qi0 + n)) / SC_TILE + 1, cur.t_lo + 1);
+        wmax = a.sink + a.m + (wraps ? a.q_len - 1 : qi0 + n);
+        t_hidden = max(wmax / SC_TILE + 1, cur.t_lo + 1);
         // with d = kv - sink - m the rows before the wrap into the next query head (i < iw) see key kv iff i >= d - qi0, the rows after it
         // iff i >= d + iw; rows beyond the last one (they shadow it) get the mask of the positions they would have - never stored
         const int iw = wraps ? a.q_len - qi0 : 64;
+        item_qi0 = qi0;
+        item_iw = iw;
         mask_a0 = -a.sink - a.m - qi0;   // + k0 + (lane & 31) - 4 half -> d - qi0 - 4 half
         mask_w = iw;                     // - 4 half
         mask_qiw = qi0 + iw;
@@ -1690,13 +1777,18 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         }
         __builtin_amdgcn_sched_barrier(0);
         // -- the block's largest logit of this lane (16 rows of one key): reference check, and the bound u for ctx keys
+        constexpr bool F16 = std::is_same<T, _Float16>::value;
+        float xf[16];   // (bf16: the 16 logits as fp32, unpacked once for the maximum and the exponent blocks)
+        if constexpr (!F16) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { xf[2 * p] = pair_lo<T>(xp[p]); xf[2 * p + 1] = pair_hi<T>(xp[p]); }
+        }
         if (tile_ctx) {   // (wave-uniform: the tile holds ctx keys; nothing but temporaries behind this branch)
             // (ctx keys are never masked.)  Each half stores the maximum of ITS 16 rows (the two are merged by the reader); lanes whose key is
             // not a ctx key store into the spare bytes behind the array
-            const uint32_t pm = pk_max8(xp);
-            const uint32_t hi = pm >> 16;
             uint32_t u16;
-            asm("v_max_f16 %0, %1, %2" : "=v"(u16) : "v"(pm), "v"(hi));
+            if constexpr (F16) u16 = max16_bits<T>(xp);
+            else u16 = __builtin_bit_cast(uint32_t, max16_f32(xf)) >> 16;
             uint32_t off = (uint32_t)((k0 >> 5) * a.n_groups * 128) + u_lane;
             if (!tile_ctx_full) off = ((uint32_t)(k0 + u_c) < (uint32_t)a.m) ? off : u_spare;   // (wave-uniform: only the tiles at the ends of the ctx range)
             asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
@@ -1712,7 +1804,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
                 load_frag1(fr[kk], lb_tag, lkb_tag, kk);
             }
             float e[4];
-            quad_exp4<T>(xp[2 * qd], xp[2 * qd + 1], L2E, nm[4 * qd], nm[4 * qd + 1], nm[4 * qd + 2], nm[4 * qd + 3], e);
+            if constexpr (F16) quad_exp4s<T>(xp[2 * qd], xp[2 * qd + 1], L2E, nmw, e);
+            else quad_exp4f(xf[4 * qd], xf[4 * qd + 1], xf[4 * qd + 2], xf[4 * qd + 3], L2E, nmw, e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float nl;   // (one instruction per statement, outputs not tied: see pass B's running maxima)
@@ -1750,18 +1843,44 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             quad_round<T, FAST>(v[0], v[1], v[2], v[3], xq[2 * qd], xq[2 * qd + 1], a.c, a.rcp);
         }
     };
-    // references of a new item: the lane's logits of its first block (acc[0], just computed by chain0); hidden (-inf) logits give reference 0,
-    // a NaN logit a NaN addend (the sum becomes NaN as the reference's softmax row does)
+    auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
+    };
+    typedef std::integral_constant<int, 0x128> ROR8;   // row_ror:8
+    typedef std::integral_constant<int, 0x124> ROR4;   // row_ror:4
+    typedef std::integral_constant<int, 0x4E> QP2;     // quad_perm:[2,3,0,1]
+    typedef std::integral_constant<int, 0xB1> QP1;     // quad_perm:[1,0,3,2]
+    // reference of a new item (round 6): ONE per wave - the largest logit of the item's first block (32 rows x 32 keys, acc[0], just computed
+    // by chain0).  Softmax is shift invariant and the partial statistics carry their reference, so any value in reach of the fp32 range does;
+    // a shared one makes the addend a scalar register (16 vector registers fewer) and the end of an item a plain sum over the 32 lanes of a
+    // half (no common-reference search, no rescaling exponentials: ~700 -> ~200 VALU instructions per item and wave).  Nothing visible: 0;
+    // a NaN logit: NaN (every sum becomes NaN; a NaN row poisons its whole KV head in the reference, attention/score.py:59-63).
     auto init_refs = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (MFMA result -> assembly block: wait states the compiler does not count)
         uint32_t xq[8];
         round16(acc[0], vis_bits(t * SC_TILE), xq);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const float xv = (k2 & 1) ? pair_hi<T>(xq[k2 >> 1]) : pair_lo<T>(xq[k2 >> 1]);
-            nm[k2] = (xv == -INFINITY) ? 0.f : -(xv * L2E);
+        const uint32_t mb = max16_bits<T>(xq) & 0xFFFFu;
+        float mx = pair_lo<T>(mb);
+        const bool isn = !(mx == mx);
+        mx = fmaxf(mx, dpp(mx, ROR8{}));
+        mx = fmaxf(mx, dpp(mx, ROR4{}));
+        mx = fmaxf(mx, dpp(mx, QP2{}));
+        mx = fmaxf(mx, dpp(mx, QP1{}));
+        {
+            const uint32_t b = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
         }
+        {
+            const uint32_t b = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+        }
+        float r = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+        if (__builtin_amdgcn_ballot_w64(isn) != 0) r = __builtin_nanf("");
+        refw = (r == -INFINITY) ? 0.f : r;
+        nmw = -(refw * L2E);
     };
     bool next_ready = false;
     // Hand-over in the third step of a tile (B = its buffer).  Every fragment of the tile has been read by now (block 3 in the
@@ -1795,15 +1914,55 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         tile_ctx_full = k0 >= a.sink && k0 + SC_TILE <= a.sink + a.m;
         const bool young = wave >= NWAVES / 2;
         auto nohook = [&]() __attribute__((always_inline)) {};
+        // a tile that holds a causal limit of the wave's rows (round 6): only the 32-key blocks that CUT the rows pay for the masks (the
+        // diagonal band of 32 rows touches one or two of the four); the blocks before it take the plain step, the blocks behind it are
+        // hidden from every row of the wave - and so is everything after them in this item: nothing to compute, nothing to prefetch (the
+        // next item opens with its own chain), only the hand-over in the third step
+        auto one = [&](f16v& accn, const f16v& accc, int kb0, auto s_tag, auto lb_tag, auto lkb_tag, auto&& hook) __attribute__((always_inline)) {
+            if constexpr (!decltype(mask_tag)::value) {
+                step(accn, accc, kb0, s_tag, std::false_type{}, lb_tag, lkb_tag, hook);
+            } else {
+#if KVZ_T2_BLOCKMASK >= 2
+                if (kb0 + 31 <= wmin) step(accn, accc, kb0, s_tag, std::false_type{}, lb_tag, lkb_tag, hook);
+                else
+#endif
+#if KVZ_T2_BLOCKMASK >= 1
+                if (kb0 <= wmax) {
+                    step(accn, accc, kb0, s_tag, std::true_type{}, lb_tag, lkb_tag, hook);
+                } else {
+                    // (the next block's chain and the fragment reads behind it are issued all the same - nothing will use them, but both
+                    // sides of the branch then define the same registers and the allocator has nothing to carry through the join)
+#pragma unroll
+                    for (int hg = 0; hg < 8; ++hg) {
+#pragma unroll
+                        for (int c = 0; c < MfmaSched<C::KK>::count(hg); ++c) {
+                            const int kk = MfmaSched<C::KK>::first(hg) + c;
+                            mfma_step(accn, kk);
+                            if (hg != 0) load_frag1(fr[kk], lb_tag, lkb_tag, kk);
+                        }
+                        if (hg == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            hook();
+#pragma unroll
+                            for (int c = 0; c < MfmaSched<C::KK>::count(0); ++c) load_frag1(fr[MfmaSched<C::KK>::first(0) + c], lb_tag, lkb_tag, MfmaSched<C::KK>::first(0) + c);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
+                step(accn, accc, kb0, s_tag, std::true_type{}, lb_tag, lkb_tag, hook);
+#endif
+            }
+        };
         if (young) __builtin_amdgcn_s_setprio(1);
-        step(acc[1], acc[0], k0, I0{}, mask_tag, b_tag, I2{}, nohook);
+        one(acc[1], acc[0], k0, I0{}, b_tag, I2{}, nohook);
         if (young) __builtin_amdgcn_s_setprio(0);
-        step(acc[0], acc[1], k0 + 32, I1{}, mask_tag, b_tag, I3{}, nohook);
+        one(acc[0], acc[1], k0 + 32, I1{}, b_tag, I3{}, nohook);
         if (young) __builtin_amdgcn_s_setprio(1);
-        step(acc[1], acc[0], k0 + 64, I2{}, mask_tag, IB1{}, I0{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
+        one(acc[1], acc[0], k0 + 64, I2{}, IB1{}, I0{}, [&]() __attribute__((always_inline)) { turnover(b_tag); });
         if (young) __builtin_amdgcn_s_setprio(0);
         // the chain issued here belongs to block 0 of the next tile; after the last tile of an item it is simply not used
-        step(acc[0], acc[1], k0 + 96, I3{}, mask_tag, IB1{}, I1{}, nohook);
+        one(acc[0], acc[1], k0 + 96, I3{}, IB1{}, I1{}, nohook);
     };
     auto tile_dispatch = [&](auto b_tag) __attribute__((always_inline)) {
         const bool masked = t * SC_TILE + SC_TILE - 1 > wmin;  // some key of the tile is hidden from some row of this wave
@@ -1832,62 +1991,21 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     };
     (void)diag0;
 
-    // partial statistics of the item's key slice: the 16 lane-partial sums of each half become 16 row sums (lane k of the half keeps row
-    // (k & 3) + 8 (k >> 2) + 4 half), stored as (reference, sum relative to fl(reference * log2e)) like the row-per-lane kernel's
-    auto finish_item = [&]() __attribute__((always_inline)) {
-        {
-            float myM = 0.f, myL = 0.f;
-            auto dpp = [](float v, auto ctrl_tag) __attribute__((always_inline)) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xf, 0xf, false));
-            };
-            typedef std::integral_constant<int, 0x128> ROR8;   // row_ror:8
-            typedef std::integral_constant<int, 0x124> ROR4;   // row_ror:4
-            typedef std::integral_constant<int, 0x4E> QP2;     // quad_perm:[2,3,0,1]
-            typedef std::integral_constant<int, 0xB1> QP1;     // quad_perm:[1,0,3,2]
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                // the 32 lanes of the half hold (reference, sum) pairs of row k: common reference = the largest one (smallest addend);
-                // all-reduce over the half: four DPP steps inside the rows of 16 lanes, then the other row of the half (v_permlane16_swap)
-                float nmin = nm[k];
-                nmin = fminf(nmin, dpp(nmin, ROR8{}));
-                nmin = fminf(nmin, dpp(nmin, ROR4{}));
-                nmin = fminf(nmin, dpp(nmin, QP2{}));
-                nmin = fminf(nmin, dpp(nmin, QP1{}));
-                {
-                    const uint32_t b = __builtin_bit_cast(uint32_t, nmin);
-                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-                    nmin = fminf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
-                }
-                float sm = lsum[k] * __builtin_amdgcn_exp2f(nmin - nm[k]);
-                sm += dpp(sm, ROR8{});
-                sm += dpp(sm, ROR4{});
-                sm += dpp(sm, QP2{});
-                sm += dpp(sm, QP1{});
-                {
-                    const uint32_t b = __builtin_bit_cast(uint32_t, sm);
-                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-                    sm = __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
-                }
-                if (l31 == k) { myM = nmin; myL = sm; }
-            }
-            {   // the reference itself: ref = half(-nm / log2e) exactly (fl(ref * log2e) / log2e is ref (1 +- 2^-23), the next 16-bit value
-                // is 2^-11 away); the stored pair is (reference, sum relative to fl(reference * log2e)) like the row-per-lane kernel's
-                const T rh = (T)(-myM * RL2E);
-                myM = (float)rh;
-            }
-            const int row = cur.rt * PA_ROWS + wave * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * half;
-            if (l31 < 16 && row < R) {
-                float2* dst = a.stats + ((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + row;
-                const float2 val = make_float2(myM, myL);
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
-                if (cur.k != u_end) {   // this block walked the unit to its end: neutral statistics in the slots beyond its own partial
-                    const float2 neutral = make_float2(-INFINITY, 0.f);
-                    const int64_t slot_stride = (int64_t)a.n_kv_heads * a.stats_stride;
-                    float2* dn = dst;
-                    for (int sl = cur.z + 1; sl < a.max_seg; ++sl) {
-                        dn += slot_stride;
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dn), "v"(neutral) : "memory");
-                    }
+    // partial statistics of the item's key slice, stored as (reference, sum relative to fl(reference * log2e)) like the row-per-lane
+    // kernel's: lane k < 16 of each half holds row (k & 3) + 8 (k >> 2) + 4 half of the wave's group
+    auto store_stats = [&](float myM, float myL) __attribute__((always_inline)) {
+        const int row = cur.rt * PA_ROWS + wave * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * half;
+        if (l31 < 16 && row < R) {
+            float2* dst = a.stats + ((int64_t)cur.z * a.n_kv_heads + cur.h) * a.stats_stride + row;
+            const float2 val = make_float2(myM, myL);
+            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+            if (cur.k != u_end) {   // this block walked the unit to its end: neutral statistics in the slots beyond its own partial
+                const float2 neutral = make_float2(-INFINITY, 0.f);
+                const int64_t slot_stride = (int64_t)a.n_kv_heads * a.stats_stride;
+                float2* dn = dst;
+                for (int sl = cur.z + 1; sl < a.max_seg; ++sl) {
+                    dn += slot_stride;
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dn), "v"(neutral) : "memory");
                 }
             }
         }
@@ -1896,6 +2014,37 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             const int val = cur.z + 1;
             asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(val) : "memory");
         }
+    };
+    // end of an item of the pipeline: the 16 lane-partial sums of each half (all against the wave's reference) become 16 row sums - four
+    // DPP steps inside the rows of 16 lanes, then the other row of the half (v_permlane16_swap).  The pipeline never moves the reference:
+    // a row sum that left the safe part of the fp32 range (a logit ~88 above the reference: inf; every visible logit ~70 below it: the
+    // terms lose their low bits; NaN inputs: NaN) flags the item, which is then redone at the end of the kernel by a slow loop that
+    // follows the logits with lane-private references.
+    auto finish_item = [&]() __attribute__((always_inline)) {
+        float myL = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float sm = lsum[k];
+            sm += dpp(sm, ROR8{});
+            sm += dpp(sm, ROR4{});
+            sm += dpp(sm, QP2{});
+            sm += dpp(sm, QP1{});
+            {
+                const uint32_t b = __builtin_bit_cast(uint32_t, sm);
+                const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+                sm = __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+            }
+            if (l31 == k) myL = sm;
+        }
+        {
+            const int c = (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * half;   // row of the group
+            const int qi = (c < item_iw) ? item_qi0 + c : c - item_iw;   // its position: keys <= sink + m + qi are visible
+            const bool stored = l31 < 16 && cur.rt * PA_ROWS + wave * 32 + c < R;
+            const bool sees = cur.t_lo * SC_TILE <= a.sink + a.m + qi;   // the first key of the item's slice
+            const bool bad = stored && (!(myL < 1.2676506e30f) || (sees && !(myL > 7.8886091e-31f)));   // 2^100, 2^-100
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(redo_word, 1u << ((cur.k - u_first) & 31));
+        }
+        store_stats(refw, myL);
     };
     chain0(I0{});
     init_refs();
@@ -1909,14 +2058,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         ++t;
         if (t < cur.t_hi) continue;
 
-        // ---- item finished.  This pipeline never moves a reference: a logit ~88 above its row's reference makes the row's sum inf (NaN
-        // inputs: NaN); such an item is redone at the end of the kernel by a slow loop that updates the references in every block ----
-        {
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) bad |= !(lsum[k] < INFINITY);
-            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(redo_word, 1u << ((cur.k - u_first) & 31));
-        }
+        // ---- item finished (finish_item flags it for the slow loop when a row sum left the safe range) ----
         finish_item();
         if (!valid(nxt)) break;
         // ---- switch to the next item: its query rows landed before the last hand-over; its first tile is in buffer pbuf ----
@@ -1962,6 +2104,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
 #pragma unroll
             for (int kk = 0; kk < C::KK; ++kk) asm volatile("" : "+v"(bq[0][kk]));
             start_item();
+            // lane-private references (a lane sees one key per block): nm = -fl(ref * log2e), moved in every block
+            float nm[16];
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) nm[k2] = NM_UNSET;
             for (int tt = cur.t_lo; tt < cur.t_hi; ++tt) {
@@ -1999,7 +2143,45 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
                 }
                 block_barrier();
             }
-            finish_item();
+            // the 32 lanes of a half hold (reference, sum) pairs of row k: common reference = the largest one (smallest addend), sums
+            // rescaled to it and added (all-reduce over the half as in finish_item)
+            float myM = 0.f, myL = 0.f;
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) {
+                float nk = nm[0], lk = lsum[0];
+#pragma unroll
+                for (int k2 = 1; k2 < 16; ++k2) {   // (rolled loop: no dynamic register index)
+                    nk = (k == k2) ? nm[k2] : nk;
+                    lk = (k == k2) ? lsum[k2] : lk;
+                }
+                float nmin = nk;
+                nmin = fminf(nmin, dpp(nmin, ROR8{}));
+                nmin = fminf(nmin, dpp(nmin, ROR4{}));
+                nmin = fminf(nmin, dpp(nmin, QP2{}));
+                nmin = fminf(nmin, dpp(nmin, QP1{}));
+                {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, nmin);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+                    nmin = fminf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+                }
+                float sm = lk * __builtin_amdgcn_exp2f(nmin - nk);
+                sm += dpp(sm, ROR8{});
+                sm += dpp(sm, ROR4{});
+                sm += dpp(sm, QP2{});
+                sm += dpp(sm, QP1{});
+                {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, sm);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+                    sm = __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+                }
+                if (l31 == k) { myM = nmin; myL = sm; }
+            }
+            {   // the reference itself: ref = 16-bit(-nm / log2e) exactly (fl(ref * log2e) / log2e is ref (1 +- 2^-23), the next 16-bit
+                // value is at least 2^-11 away)
+                const T rh = (T)(-myM * RL2E);
+                myM = (float)rh;
+            }
+            store_stats(myM, myL);
         }
     }
 }
@@ -2059,6 +2241,7 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
     __shared__ uint32_t s_list[64 * BD2_MAXPASS];
     __shared__ int s_n, s_base, s_poison;
     if (tid == 0) { s_n = 0; s_poison = 0; }
+    __syncthreads();   // (the flags are initialised before any wave raises s_poison below)
     const int ng = a.n_groups;
     const int npass = (ng + 63) / 64;
     const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 64);   // per group: 8 uint4 (two halves of 32 keys)
@@ -2072,7 +2255,12 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
             const uint4 u0 = ub[g * 8 + oct], u1 = ub[g * 8 + 4 + oct];
             auto pkmax = [](uint32_t x, uint32_t y) __attribute__((always_inline)) -> uint32_t {
                 uint32_t r;
-                asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+                if constexpr (std::is_same<T, _Float16>::value) {
+                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+                } else {   // bf16: no packed maximum - both halves through fp32 (the result is one of the inputs: the way back is exact)
+                    const float lo = fmaxf(pair_lo<T>(x), pair_lo<T>(y)), hi = fmaxf(pair_hi<T>(x), pair_hi<T>(y));
+                    r = (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xFFFF0000u);
+                }
                 return r;
             };
             uu[p] = make_uint4(pkmax(u0.x, u1.x), pkmax(u0.y, u1.y), pkmax(u0.z, u1.z), pkmax(u0.w, u1.w));
@@ -2155,7 +2343,6 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
 constexpr int SB_WAVES = 4;
 template <typename T, int D, bool FAST>
 __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(ScoreArgs a) {
-    static_assert(std::is_same<T, _Float16>::value, "fp16 only (quad_round)");
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a pair, swizzled like a key tile
@@ -2523,46 +2710,33 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     a.row_splits = score_row_splits(Hkv, a.G, a.q_len, a.m);
     const int ctiles = (a.m + PB_COLS - 1) / PB_COLS;
     // exact pruning of pass B (round 5; knob score_prune: 0 = two full passes; 1 = key-per-lane pass A, every block of pass B (checks);
-    // 3 = candidate pairs only; 4 = every pair through the sparse kernel (checks)).  fp16, deferred-log path.
+    // 3 = candidate pairs only; 4 = every pair through the sparse kernel (checks)).  Both dtypes (round 6); deferred-log path.
     int prune = 0;
-    if constexpr (std::is_same<T, _Float16>::value) {
-        if (a.unit_nseg && a.n_groups <= 64 * BD2_MAXPASS && a.nkb < 16384 && Hkv < 128 && a.q_len >= 32) prune = tunable(TUNE_SCORE_PRUNE);
-        if (prune >= 3 && !a.log_out) prune = 1;   // (the sparse pass merges through the log buffer)
-    }
-    if constexpr (std::is_same<T, _Float16>::value) {
-        if (prune) {
+    if (a.unit_nseg && a.n_groups <= 64 * BD2_MAXPASS && a.nkb < 16384 && Hkv < 128 && a.q_len >= 32) prune = tunable(TUNE_SCORE_PRUNE);
+    if (prune >= 3 && !a.log_out) prune = 1;   // (the sparse pass merges through the log buffer)
+    if (prune) {
+        {
+            ProfScope ps("score_rowstat", stream);
+            hipLaunchKernelGGL((score_rowstatT2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
+            KVZ_CHECK_LAUNCH("score_rowstatT2_kernel");
+        }
+        if (prune >= 3) {
+            a.all_pairs = (prune == 4);
             {
-                ProfScope ps("score_rowstat", stream);
-                hipLaunchKernelGGL((score_rowstatT2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
-                KVZ_CHECK_LAUNCH("score_rowstatT2_kernel");
-            }
-            if (prune >= 3) {
-                a.all_pairs = (prune == 4);
-                {
-                    ProfScope ps("score_bounds", stream);
-                    hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
-                    KVZ_CHECK_LAUNCH("score_merge_kernel");
-                    hipLaunchKernelGGL((score_bounds2_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
-                    KVZ_CHECK_LAUNCH("score_bounds2_kernel");
-                }
-                {
-                    ProfScope ps("score_colmax", stream);
-                    hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST>), dim3(2 * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
-                    KVZ_CHECK_LAUNCH("score_colmax_sparse_kernel");
-                }
-                return KVZ_OK;
+                ProfScope ps("score_bounds", stream);
+                hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
+                KVZ_CHECK_LAUNCH("score_merge_kernel");
+                hipLaunchKernelGGL((score_bounds2_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
+                KVZ_CHECK_LAUNCH("score_bounds2_kernel");
             }
             {
                 ProfScope ps("score_colmax", stream);
-                hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
+                hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST>), dim3(2 * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
+                KVZ_CHECK_LAUNCH("score_colmax_sparse_kernel");
             }
-            KVZ_CHECK_LAUNCH("score_colmax3_kernel");
+            return KVZ_OK;
         }
-    }
-    if (prune) {
-        // (both passes launched above)
-    } else {
-    if (a.unit_nseg) {  // (null: the row statistics came out of the scoring forward's attention kernel - kvz_flash_fwd_window)
+    } else if (a.unit_nseg) {  // (null: the row statistics came out of the scoring forward's attention kernel - kvz_flash_fwd_window)
         ProfScope ps("score_rowstat", stream);
         hipLaunchKernelGGL((score_rowstat2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
         KVZ_CHECK_LAUNCH("score_rowstat2_kernel");
@@ -2572,8 +2746,7 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     {
         ProfScope ps("score_colmax", stream);
         hipLaunchKernelGGL((score_colmax3_kernel<T, D, FAST>), dim3(ctiles * a.row_splits * Hkv), dim3(PB_WAVES * 64), 0, stream, a);
-    }
-    KVZ_CHECK_LAUNCH("score_colmax3_kernel");
+        KVZ_CHECK_LAUNCH("score_colmax3_kernel");
     }
     if (a.log_out) return KVZ_OK;  // (the row slices were merged by the atomics; kvz_score_finalize_log turns the buffer into scores)
     hipLaunchKernelGGL((score_finalize_kernel<T>), dim3((a.m + 255) / 256, Hkv), dim3(256), 0, stream, a.colpart,

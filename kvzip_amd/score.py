@@ -133,11 +133,11 @@ class KVScore:
 
     # ---- asynchronous scoring: bookkeeping -----------------------------------------------------------------
     def _auto_streams(self, lib, dtype) -> int:
-        """side streams of the scoring calls: ``n_score_streams`` if set, else three where the pruned call (knob ``score_prune``, fp16) runs
-        and two for the two-pass call (bf16, or the knob off)."""
+        """side streams of the scoring calls: ``n_score_streams`` if set, else three where the pruned call (knob ``score_prune``) runs and
+        two for the two-pass call (the knob off)."""
         if self.n_score_streams:
             return max(1, int(self.n_score_streams))
-        return 3 if (dtype == torch.float16 and lib.kvz_debug_get_tunable(b"score_prune") >= 3) else 2
+        return 3 if lib.kvz_debug_get_tunable(b"score_prune") >= 3 else 2
 
     @property
     def score(self):
@@ -298,6 +298,7 @@ class KVScore:
             side = cur
         else:
             if len(self._score_side) < nstreams:
+                self._wait_score(finalize=False)  # (the pool may be rebuilt: nothing may be pending on the streams it replaces)
                 self._score_side = _side_streams(dev, nstreams)
             st = self._score_side[slot]
             side = st.cuda_stream
@@ -392,6 +393,7 @@ class KVScore:
             side = cur
         else:
             if len(self._score_side) < nstreams:
+                self._wait_score(finalize=False)  # (see _get_score)
                 self._score_side = _side_streams(dev, nstreams)
             sst = self._score_side[slot]
             side = sst.cuda_stream

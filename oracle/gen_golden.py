@@ -463,6 +463,71 @@ def gen_uniform_ties(KVScore):
     np.savez_compressed(os.path.join(OUT, "g13_uniform_ties.npz"), **out)
 
 
+def gen_far_context(KVScore):
+    """G14 (round 6): the REFERENCE's _get_score (attention/score.py:36-65) on the LAST TWO scoring chunks of one layer of a full
+    131 072-token context at the Qwen2.5-7B head geometry - chunk starts 128 032 / 130 032, key length 133 k: pins the far end of the
+    cache (64-bit offsets, the short last chunk of 1 072 tokens) against the reference itself.  Only the 3 072 x Hkv scores per dtype
+    are stored; the inputs come from a seed (tests/e2e_inputs.py:make_far) and carry a checksum."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_inputs as E
+    geom = E.GEOM_FAR
+    out = {}
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        K0, far = E.make_far(dt)
+        sc = KVScore()
+        sc.n_heads_kv, sc.dtype, sc.device, sc.n_layers = geom["Hkv"], dt, "cpu", 1
+        sc.sink = geom["sink"]
+        sc.init_score()
+        # the score buffer of the reference grows by concatenation (score.py:30-34): start it at the first stored chunk
+        for (st, en, q_len, q, kr) in far:
+            sc.start_idx, sc.end_idx = st, en
+            sc._get_score(q, torch.cat([K0, kr], dim=2), 0)
+        score = sc.score[0]                                # [1, Hkv, sum of the two chunk lengths]
+        assert score.shape[-1] == far[-1][1] - far[0][0]
+        out[f"{tag}/score"] = bits(score)
+        out[f"{tag}/checksum"] = np.array([E.checksum([K0], [[(q, kr)] for (_, _, _, q, kr) in far])], dtype=np.int64)
+        print("g14", tag, "chunks", [(st, en, ql) for (st, en, ql, _, _) in far], "scores", tuple(score.shape), flush=True)
+    out["geom"] = np.array([geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g14_far_context.npz"), **out)
+
+
+def gen_full_layer(KVScore):
+    """G15 (round 6): ONE FULL LAYER of the headline context from the REFERENCE - all 66 scoring chunks of a 131 072-token context at the
+    Qwen2.5-7B head geometry through _get_score (attention/score.py:36-65), then _threshold at ratio 0.3 (:88-102): 524 288 scores per
+    dtype, threshold, packed mask, kept per head.  Replaces the extrapolated flip count at the headline size by a measured one (per
+    layer).  ~4 minutes of CPU per dtype."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_inputs as E
+    geom = E.GEOM_FAR
+    out = {}
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        it = E.stream_full(dt)
+        K0 = next(it)
+        acc = E.checksum_update(0, K0)
+        sc = KVScore()
+        sc.n_heads_kv, sc.dtype, sc.device, sc.n_layers = geom["Hkv"], dt, "cpu", 1
+        sc.sink = geom["sink"]
+        sc.init_score()
+        for ci, (st, en, q_len, q, kr) in enumerate(it):
+            acc = E.checksum_update(E.checksum_update(acc, q), kr)
+            sc.start_idx, sc.end_idx = st, en
+            sc._get_score(q, torch.cat([K0, kr], dim=2), 0)
+            if ci % 8 == 0:
+                print("g15", tag, "chunk", ci, flush=True)
+        score = sc.score[0]
+        assert score.shape[-1] == geom["N"]
+        valid, thres = sc._threshold(sc.score, 0.3)
+        out[f"{tag}/score"] = bits(score)
+        out[f"{tag}/thres"] = np.array([thres], dtype=np.float64)
+        out[f"{tag}/valid"] = np.packbits(valid.numpy().reshape(-1))
+        out[f"{tag}/kept"] = valid.sum(-1).reshape(geom["Hkv"]).numpy().astype(np.int32)
+        out[f"{tag}/checksum"] = np.array([acc], dtype=np.int64)
+        print("g15", tag, "thres", thres, "kept", int(valid.sum()), "of", valid.numel(), flush=True)
+        del K0
+    out["geom"] = np.array([geom[k] for k in ("L", "H", "Hkv", "D", "sink", "N", "chunk")], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g15_full_layer.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -477,6 +542,13 @@ def main():
         return
     if "--only-e2e-llama" in sys.argv:
         gen_e2e_llama(KVScore)
+        return
+    if "--only-round6" in sys.argv:
+        gen_far_context(KVScore)
+        gen_full_layer(KVScore)
+        return
+    if "--only-full-layer" in sys.argv:
+        gen_full_layer(KVScore)
         return
     if "--only-round5" in sys.argv:
         gen_e2e_ratios(KVScore)
@@ -493,6 +565,8 @@ def main():
     gen_e2e_llama(KVScore)
     gen_e2e_ratios(KVScore)
     gen_uniform_ties(KVScore)
+    gen_far_context(KVScore)
+    gen_full_layer(KVScore)
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print(f"wrote {OUT}: {total / 1e6:.2f} MB")
 

@@ -1,4 +1,4 @@
-"""The exact-pruning variant of the scoring call (round 5, knob ``score_prune``: 3 = the fp16 default, 0 = the two-pass call): a key-per-lane pass A that also writes
+"""The exact-pruning variant of the scoring call (round 5; round 6: both dtypes; knob ``score_prune``: 3 = the default, 0 = the two-pass call): a key-per-lane pass A that also writes
 per-group maxima, merged statistics + group bounds, a compacted list of candidate (32-row group, 32-key block) pairs, a sparse pass B over
 those pairs.
 
@@ -57,22 +57,24 @@ def _inputs(H, Hkv, D, sink, N, q_len, seed, dtype=torch.float16):
     (4, 2, 64, 16, 500, 16 + 100, 300, 310),        # D = 64
     (16, 2, 64, 30, 1200, 30 + 400, 513, 77),       # G = 8, rows spanning several query heads per tile
 ])
-def test_pruned_scoring_call(H, Hkv, D, sink, N, start, m, q_len):
-    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=H * 1000 + m)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_pruned_scoring_call(H, Hkv, D, sink, N, start, m, q_len, dtype):
+    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=H * 1000 + m, dtype=dtype)
     want = orc.get_score(q, k, sink, start, start + m)[0]
     qd, kd = q.to(DEV), k.to(DEV)
     got = {p: _score_log(qd, kd, sink, start, start + m, p) for p in (1, 3, 4)}
-    check_score_parity(f"prune/{H}x{Hkv}x{D}/m{m}", got[3], want)
+    check_score_parity(f"prune/{H}x{Hkv}x{D}/m{m}/{dtype}", got[3], want)
     assert _same_bits(got[3], got[1]), "sparse pass B differs from the full pass B on the same statistics"
     assert _same_bits(got[3], got[4]), "candidate pairs differ from all pairs"
 
 
-def test_pruned_scoring_call_on_copy_like_logits():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_pruned_scoring_call_on_copy_like_logits(dtype):
     """peaky rows (the repeat prompt's queries resemble the keys they repeat): few candidate pairs, large spread of the row statistics."""
     H, Hkv, D, sink, N, start, m, q_len = 14, 2, 128, 32, 3000, 32 + 500, 2000, 2026
-    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=77)
+    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=77, dtype=dtype)
     kk = k[:, :, start:start + m].repeat_interleave(H // Hkv, dim=1)
-    q[:, :, :m] = (q[:, :, :m].float() * 0.5 + kk.float() * 0.35).half()
+    q[:, :, :m] = (q[:, :, :m].float() * 0.5 + kk.float() * 0.35).to(dtype)
     want = orc.get_score(q, k, sink, start, start + m)[0]
     qd, kd = q.to(DEV), k.to(DEV)
     got1, got3 = _score_log(qd, kd, sink, start, start + m, 1), _score_log(qd, kd, sink, start, start + m, 3)
@@ -80,9 +82,10 @@ def test_pruned_scoring_call_on_copy_like_logits():
     assert _same_bits(got3, got1)
 
 
-def test_pruned_scoring_call_propagates_nan_like_the_product_path():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_pruned_scoring_call_propagates_nan_like_the_product_path(dtype):
     H, Hkv, D, sink, N, start, m, q_len = 8, 4, 128, 32, 1500, 32 + 300, 600, 610
-    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=5)
+    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=5, dtype=dtype)
     q[0, 3, 77, 5] = float("nan")        # query head 3 -> KV head 1
     k[0, 2, start + 11, 7] = float("inf")  # a ctx key of KV head 2
     qd, kd = q.to(DEV), k.to(DEV)
@@ -93,12 +96,13 @@ def test_pruned_scoring_call_propagates_nan_like_the_product_path():
     check_score_parity("prune/nan/clean heads", got[[0, 3]], want[[0, 3]])
 
 
-def test_logits_outside_the_range_of_the_fixed_references_are_redone():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_logits_outside_the_range_of_the_fixed_references_are_redone(dtype):
     """the key-per-lane pass keeps the reference of a row where its first key block put it; a later logit ~88 above it makes the row's sum
     non-finite, and the kernel redoes such an item at its end with references that follow the logits: same bounds against the oracle, and
     the sparse pass still returns the bits of the full pass B on those statistics."""
     H, Hkv, D, sink, N, start, m, q_len = 8, 4, 128, 32, 1500, 32 + 300, 600, 610
-    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=9)
+    q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=9, dtype=dtype)
     k[0, 1, start + 400] *= 40.0
     k[0, 2, -100] *= 60.0
     k[0, 3, 5] *= 50.0
@@ -109,14 +113,14 @@ def test_logits_outside_the_range_of_the_fixed_references_are_redone():
     check_score_parity("prune/spikes", got3, want)
     assert _same_bits(got3, got1)
     # ... and the next call with ordinary inputs is right as well (the per-block redo masks clear themselves)
-    q2, k2 = _inputs(H, Hkv, D, sink, N, q_len, seed=10)
+    q2, k2 = _inputs(H, Hkv, D, sink, N, q_len, seed=10, dtype=dtype)
     want2 = orc.get_score(q2, k2, sink, start, start + m)[0]
     check_score_parity("prune/after a redo", _score_log(q2.to(DEV), k2.to(DEV), sink, start, start + m, 3), want2)
 
 
-@pytest.mark.parametrize("dtype,q_len", [(torch.bfloat16, 610), (torch.float16, 20)])
+@pytest.mark.parametrize("dtype,q_len", [(torch.float16, 20), (torch.bfloat16, 20)])
 def test_knob_is_ignored_where_the_path_does_not_apply(dtype, q_len):
-    """bf16 (no packed 16-bit maxima) and chunks of fewer than 32 query positions take the product kernels whatever the knob says."""
+    """chunks of fewer than 32 query positions take the two-pass kernels whatever the knob says."""
     H, Hkv, D, sink, N, start, m = 4, 2, 128, 8, 900, 8 + 100, 300
     q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=3, dtype=dtype)
     qd, kd = q.to(DEV), k.to(DEV)
@@ -124,14 +128,14 @@ def test_knob_is_ignored_where_the_path_does_not_apply(dtype, q_len):
 
 
 def test_reference_fixtures_end_to_end_with_the_pruning_path_on():
-    """the reference-generated end-to-end fixtures (scores -> threshold -> mask of 64 000 / 512 000 / 128 000 scores, fp16) through the whole
+    """the reference-generated end-to-end fixtures (scores -> threshold -> mask of 64 000 / 512 000 / 128 000 scores, both dtypes) through the whole
     cache object with the knob preset by the environment (a fresh process: the knob is read when the library is loaded)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KVZIP_SCORE_PRUNE="3")
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_e2e_parity.py"), "-x", "-q", "-m", "gpu", "-k", "f16"],
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_e2e_parity.py"), "-x", "-q", "-m", "gpu"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-1000:]
     assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-500:]

@@ -266,3 +266,32 @@ def test_next_token_follows_hf_generate_knobs():
     # degenerate knobs reduce to greedy
     assert torch.equal(M.next_token(logits, {"do_sample": True, "top_k": 1}, g), logits.argmax(-1, keepdim=True))
     assert torch.equal(M.next_token(logits, {"do_sample": True, "top_p": 1e-9}, g), logits.argmax(-1, keepdim=True))
+
+
+def test_bench_parity_gate_uses_the_test_suite_bounds():
+    """bench.py turns its parity sample into an assertion (exit code 3): its bounds are the ones of conftest.SCORE_BOUNDS, and the
+    checker flags exactly what they forbid."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from conftest import SCORE_BOUNDS
+    assert bench.PARITY_BOUNDS == {"f16": SCORE_BOUNDS[torch.float16], "bf16": SCORE_BOUNDS[torch.bfloat16]}
+    n = 20000
+    d = torch.zeros(n, dtype=torch.int64)
+    assert bench.parity_violations("f16", d) == []
+    d[:40] = 1                                          # 0.2 % not identical: inside the fp16 bound, outside the bf16 one
+    assert bench.parity_violations("f16", d) == [] and len(bench.parity_violations("bf16", d)) == 1
+    d[0] = 9                                            # worst step count
+    assert len(bench.parity_violations("f16", d)) == 1
+    # masks: a flip is tolerated only where a non-identical score sits at the threshold
+    want = torch.linspace(0.01, 0.99, n).half()
+    got = want.clone()
+    d = torch.zeros(n, dtype=torch.int64)
+    v_ref = want.float() > 0.5
+    v_got = v_ref.clone()
+    j = int(torch.nonzero(v_ref)[0])                    # first entry above the threshold
+    v_got[j] = False
+    assert len(bench.parity_violations("f16", d, want, got, v_ref, v_got, 0.5)) == 1      # identical score, flipped entry: never
+    d[j] = 1
+    assert bench.parity_violations("f16", d, want, got, v_ref, v_got, float(want[j - 1])) == []

@@ -317,3 +317,31 @@ def test_oracle_threshold_on_e2e_llama_fixture():
 
 def to_bits_t(t):
     return t.contiguous().view(torch.int16)
+
+
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+def test_oracle_pinned_at_the_far_end_of_the_headline_context(tag):
+    """G14 (round 6, reference-generated): the last two scoring chunks of one layer of a 131 072-token context at the Qwen2.5-7B head
+    geometry - chunk starts 128 032 / 130 032, key length 133 k, the short last chunk (1 072 tokens).  The oracle reproduces the
+    reference's scores bit for bit there too."""
+    import e2e_inputs as E
+    g = load_golden("g14_far_context.npz")
+    geom = E.GEOM_FAR
+    dt = torch.float16 if tag == "f16" else torch.bfloat16
+    K0, far = E.make_far(dt)
+    assert E.checksum([K0], [[(q, kr)] for (_, _, _, q, kr) in far]) == int(g[f"{tag}/checksum"][0])
+    want = from_bits(g[f"{tag}/score"], tag == "bf16")
+    got = torch.cat([orc.get_score(q, torch.cat([K0, kr], dim=2), geom["sink"], st, en) for (st, en, _, q, kr) in far], dim=-1)
+    assert torch.equal(to_bits_t(got), to_bits_t(want))
+
+
+def test_oracle_threshold_on_the_full_layer_fixture():
+    """G15 (round 6): the oracle's threshold / mask on the reference's own 524 288 scores of one full layer of the headline context."""
+    g = load_golden("g15_full_layer.npz")
+    L, H, Hkv, D, sink, N, chunk = [int(x) for x in g["geom"]]
+    for tag, bf in (("f16", False), ("bf16", True)):
+        want = from_bits(g[f"{tag}/score"], bf).view(1, 1, Hkv, N)
+        valid, thres = orc.threshold([want[0]], 0.3)
+        assert thres == float(g[f"{tag}/thres"][0])
+        assert np.array_equal(np.packbits(valid.numpy().reshape(-1)), g[f"{tag}/valid"])
+        assert np.array_equal(valid.sum(-1).reshape(Hkv).numpy().astype(np.int32), g[f"{tag}/kept"])

@@ -11,6 +11,7 @@ from kvzip_amd import _lib, ops
 
 def main():
     lib = _lib.load(); dev = "cuda:0"
+    dt = torch.bfloat16 if os.environ.get("PRUNE_DTYPE") == "bf16" else torch.float16
     variants = [int(x) for x in os.environ.get("PRUNE_VARIANTS", "0,1,2,3").split(",")]
     shapes = [(4, 7, 2000, 128, 32, 2026, 60000, "gauss"), (4, 7, 2000, 128, 32, 2026, 60000, "copy"), (4, 7, 2000, 128, 32, 2013, 0, "gauss"),
               (2, 4, 777, 128, 4, 790, 1000, "gauss"), (8, 4, 2000, 128, 32, 2026, 3000, "gauss"), (1, 1, 33, 128, 0, 40, 5, "gauss"),
@@ -21,12 +22,12 @@ def main():
         N = s0 + m + 1000
         klen = sink + N + q_len
         g = torch.Generator(device=dev).manual_seed(1)
-        q = torch.randn(1, Hkv * G, q_len, D, generator=g, device=dev).half()
-        k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).half()
+        q = torch.randn(1, Hkv * G, q_len, D, generator=g, device=dev).to(dt)
+        k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
         start = sink + s0
         if kind == "copy":   # repeat-prompt-like: the queries of position i resemble the key of ctx position i
             kk = k[:, :, start:start + m].repeat_interleave(G, dim=1)
-            q[:, :, :m] = (q[:, :, :m] * 0.5 + kk * 1.5).half()
+            q[:, :, :m] = (q[:, :, :m] * 0.5 + kk * 1.5).to(dt)
         if kind == "nan":
             q[0, 3, 77, 5] = float("nan")      # poisons KV head 0 only
         if kind == "spike":                    # a few keys with logits far above everything before them: the fallback must take over
@@ -47,7 +48,7 @@ def main():
             if os.environ.get("PRUNE_FORCE_REDO"): ws.fill_(255)   # every block of the key-per-lane pass redoes its items in the slow loop
             lib.kvz_debug_set_tunable(b"score_prune", pr)
             call()
-            o = torch.empty(Hkv, m, dtype=torch.float16, device=dev)
+            o = torch.empty(Hkv, m, dtype=dt, device=dev)
             ops.check(lib.kvz_score_finalize_log(log.data_ptr(), log.numel(), o.data_ptr(), ops._dtype_code(q.dtype), st), "finalize")
             out[pr] = o.float().clone()
             t = {}

@@ -10,7 +10,8 @@ def child():
     Hkv, G, m, D, sink, N = 4, 7, 2000, 128, 32, 131072
     q_len = m + 26; klen = sink + N + q_len
     g = torch.Generator(device=dev).manual_seed(0)
-    q = torch.randn(1, Hkv * G, q_len, D, generator=g, device=dev).half(); k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).half()
+    dt = torch.bfloat16 if os.environ.get("PRUNE_DTYPE") == "bf16" else torch.float16
+    q = torch.randn(1, Hkv * G, q_len, D, generator=g, device=dev).to(dt); k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
     start = sink + 60000
     r = {}
     for pr in (0, 1):
