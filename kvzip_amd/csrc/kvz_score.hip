@@ -68,6 +68,10 @@ struct ScoreArgs {
     uint32_t* redo;      // [PLAN_MAX_BLOCKS] per block of the key-per-lane pass: items to be redone by its slow loop (self-clearing)
     int n_groups, nkb;
     int all_pairs;       // (debug knob: every pair is a candidate)
+    // ---- candidates at KEY granularity (round 6: score_bounds3_kernel, score_colmax_keys_kernel)
+    uint32_t* gcount;    // [Hkv, n_groups]            candidate keys of row group g (zeroed by score_merge_kernel, filled by score_bounds3_kernel)
+    uint32_t* klist;     // [Hkv, n_groups, kcap]      their ctx indices j (any order)
+    int kcap;            // nkb * 32
 };
 
 // the same chain, result kept as the 16-bit value (maxima are taken on 16-bit values, the exp2 / subtraction
@@ -2218,6 +2222,7 @@ __global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
         const float qnan = __builtin_nanf("");
         const bool any = rt * PA_ROWS + (int)(threadIdx.x & ~31u) < R;
         a.gbound[(int64_t)h * a.n_groups + grp] = gbad ? make_float2(qnan, qnan) : (any ? make_float2(mx, mn) : make_float2(-INFINITY, -INFINITY));
+        a.gcount[(int64_t)h * a.n_groups + grp] = 0;
     }
     if (unit == 0 && (int)threadIdx.x < a.n_kv_heads) a.counter[threadIdx.x] = 0;
 }
@@ -2341,13 +2346,37 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds2_kernel(ScoreArgs a)
 // computed), and holds ONE running maximum per lane; when the key block changes (or the share ends) the two halves of the wave are
 // merged and the 32 maxima go out with the same atomic minimum on the log-score patterns that merges the row slices of the dense pass.
 constexpr int SB_WAVES = 4;
-template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(ScoreArgs a) {
+#ifndef KVZ_SB_NBUF
+#define KVZ_SB_NBUF 2   // staging buffers per wave of the pair-level sparse pass (knob score_prune = 5)
+#endif
+#ifndef KVZ_SB_OCC1
+#define KVZ_SB_OCC1 3   // blocks per CU of the one-buffer sparse pass (4: 128 registers per lane - two of them spill)
+#endif
+// log-score of four logits: t_k = float(x_k) + n_k (fp16: the mixed-precision fma reads the 16-bit half and adds in one instruction -
+// x * 1.0 + n is the same single rounding as the conversion followed by the addition)
+template <typename T>
+__device__ static inline void quad_addn(uint32_t xa, uint32_t xb, float n0, float n1, float n2, float n3, float (&t)[4]) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        asm("v_fma_mix_f32 %[t0], %[xa], 1.0, %[n0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t2], %[xb], 1.0, %[n2] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t1], %[xa], 1.0, %[n1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t3], %[xb], 1.0, %[n3] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3])
+            : [xa] "v"(xa), [xb] "v"(xb), [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2), [n3] "v"(n3));
+    } else {
+        t[0] = pair_lo<T>(xa) + n0; t[1] = pair_hi<T>(xa) + n1; t[2] = pair_lo<T>(xb) + n2; t[3] = pair_hi<T>(xb) + n3;
+    }
+}
+// NBUF = 2 (round 5): a wave stages the rows of the next pair into its second buffer while it computes the current one; 67 KiB of LDS per
+// block: two blocks = eight waves per CU.  NBUF = 1 (round 6): ONE buffer per wave - the rows of the next pair are staged into it as soon
+// as the fragments of the current pair sit in registers (before its MFMAs: the same distance ahead), half the LDS, SIXTEEN waves per CU.
+template <typename T, int D, bool FAST, int NBUF>
+__global__ __launch_bounds__(SB_WAVES * 64, NBUF == 1 ? KVZ_SB_OCC1 : 2) void score_colmax_sparse_kernel(ScoreArgs a) {
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
     constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a pair, swizzled like a key tile
     constexpr int PB_BYTES = QG_BYTES + 256;         // + their 32 statistics n_r (written twice: one 64-lane dword DMA)
-    __shared__ __attribute__((aligned(16))) char lds[SB_WAVES * 2 * PB_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[SB_WAVES * NBUF * PB_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -2369,7 +2398,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
     if (lo >= hi) return;
     const int64_t head_cap = (int64_t)a.nkb * a.n_groups;
     const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    char* const wl = lds + wave * 2 * PB_BYTES;
+    char* const wl = lds + wave * NBUF * PB_BYTES;
     const uint32_t wl0 = lds_addr(wl);
     FragAddr<D> fa0;
     fa0.init(wl, l31, half);
@@ -2437,13 +2466,17 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
     };
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4v* lds_f4_t;
-    auto compute = [&](auto b_tag) __attribute__((always_inline)) {
+    auto compute = [&](auto b_tag, auto&& restage) __attribute__((always_inline)) {
         constexpr int B = decltype(b_tag)::value;
         u32x4 fq[C::KK];
         frag_load<D>(fq, fa0, B * PB_BYTES);
         f4v nn[4];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) nn[qd] = *(lds_f4_t)(uintptr_t)(nb0 + (uint32_t)(B * PB_BYTES + 32 * qd));
+        if constexpr (NBUF == 1) {   // the buffer is free once the reads have returned: the rows of the next pair go into it now
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            restage();
+        }
         f16v acc = zero16;
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fq[kk]), __builtin_bit_cast(v8, bk[kk]), acc);
@@ -2457,8 +2490,10 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
             uint32_t xa, xb;
             quad_round<T, FAST>(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3], xa, xb, a.c, a.rcp);
             // accumulators 4 qd .. 4 qd + 3 are rows 8 qd + 4 half + (0..3)
-            const float t0 = pair_lo<T>(xa) + nn[qd].x, t1 = pair_hi<T>(xa) + nn[qd].y, t2 = pair_lo<T>(xb) + nn[qd].z, t3 = pair_hi<T>(xb) + nn[qd].w;
-            best = fmaxf(fmaxf(best, fmaxf(t0, t1)), fmaxf(t2, t3));
+            float t[4];
+            quad_addn<T>(xa, xb, nn[qd].x, nn[qd].y, nn[qd].z, nn[qd].w, t);
+            best = fmaxf(fmaxf(best, t[0]), t[1]);   // (two v_max3_f32)
+            best = fmaxf(fmaxf(best, t[2]), t[3]);
         }
     };
     typedef std::integral_constant<int, 0> I0;
@@ -2473,24 +2508,297 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void score_colmax_sparse_kernel(S
         const uint32_t ev = a.entries[hcur * head_cap + (b0 - hbase) + min(lane, nb - 1)];
         auto entry = [&](int i) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ev, i); };
         stage(0, entry(0));
-        for (int i = 0; i < nb; i += 2) {
-            const bool has1 = i + 1 < nb;
-            if (has1) stage(1, entry(i + 1));
-            keys_for(entry(i));   // (a key block's loads are issued before the wait for the staged rows: one round trip, not two)
-            if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
-            else stage_wait();
-            compute(I0{});
-            if (!has1) break;
-            const bool has2 = i + 2 < nb;
-            if (has2) stage(0, entry(i + 2));
-            keys_for(entry(i + 1));
-            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
-            else stage_wait();
-            compute(I1{});
+        if constexpr (NBUF == 1) {
+            for (int i = 0; i < nb; ++i) {
+                keys_for(entry(i));   // (a key block's loads are issued before the wait for the staged rows: one round trip, not two)
+                stage_wait();
+                compute(I0{}, [&]() __attribute__((always_inline)) { if (i + 1 < nb) stage(0, entry(i + 1)); });
+            }
+        } else {
+            auto none = [&]() __attribute__((always_inline)) {};
+            for (int i = 0; i < nb; i += 2) {
+                const bool has1 = i + 1 < nb;
+                if (has1) stage(1, entry(i + 1));
+                keys_for(entry(i));
+                if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
+                else stage_wait();
+                compute(I0{}, none);
+                if (!has1) break;
+                const bool has2 = i + 2 < nb;
+                if (has2) stage(0, entry(i + 2));
+                keys_for(entry(i + 1));
+                if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGE_OPS) : "memory");
+                else stage_wait();
+                compute(I1{}, none);
+            }
         }
         b0 += nb;
     }
     flush();
+}
+
+// ---- candidates at KEY granularity (round 6) ------------------------------------------------------------------------------------------------
+// A (32-row group, 32-key block) pair is recomputed in full - 1024 logits - although all it is needed for is, typically, ONE key: every key
+// has its argmax group (and the one or two groups whose bound cannot rule them out), so a key block of 32 keys names ~55 of the 448 groups
+// (18 % of the pairs on the benchmark's inputs).  Turned around, a row group is named by ~31 KEYS of the whole chunk: score_bounds3_kernel
+// applies the same exact test per (group, key) - u_gj + nmax_g >= LB_j - and appends key j to the list of group g; score_colmax_keys_kernel
+// takes a group's 32 query rows as the A operand and GATHERS 32 of its candidate keys as the B operand (one key per lane), so one 32x32
+// block of logits serves 32 candidates: ~1.6 blocks per group instead of ~11 pairs, a seventh of the matrix and rounding-chain work.  The
+// logit of a (row, key) pair does not depend on where it sits in an MFMA tile, so the column maxima are the bits of the full pass B.
+template <typename T>
+__global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a) {
+    const int kb = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int oct = tid & 3, grow = tid >> 2;   // 8 keys [8 oct, 8 oct + 8) of group (pass * 64 + grow)
+    __shared__ float s_part[64][33];
+    __shared__ float s_lb8[8][32];
+    __shared__ float s_lb[32];
+    __shared__ uint32_t s_list[64 * BD2_MAXPASS * 2];   // work items opened by this block: at most two per group (32 keys)
+    __shared__ int s_n, s_base, s_poison;
+    if (tid == 0) { s_n = 0; s_poison = 0; }
+    __syncthreads();   // (the flags are initialised before any wave touches them below)
+    const int ng = a.n_groups;
+    const int npass = (ng + 63) / 64;
+    const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 64);   // per group: 8 uint4 (two halves of 32 keys)
+    const float2* gb = a.gbound + (int64_t)h * ng;
+    uint4 uu[BD2_MAXPASS];
+    float2 bb[BD2_MAXPASS];
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        const int g = min(p * 64 + grow, ng - 1);
+        if (p < npass) {
+            const uint4 u0 = ub[g * 8 + oct], u1 = ub[g * 8 + 4 + oct];
+            auto pkmax = [](uint32_t x, uint32_t y) __attribute__((always_inline)) -> uint32_t {
+                uint32_t r;
+                if constexpr (std::is_same<T, _Float16>::value) {
+                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+                } else {   // bf16: no packed maximum - both halves through fp32 (the result is one of the inputs: the way back is exact)
+                    const float lo = fmaxf(pair_lo<T>(x), pair_lo<T>(y)), hi = fmaxf(pair_hi<T>(x), pair_hi<T>(y));
+                    r = (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xFFFF0000u);
+                }
+                return r;
+            };
+            uu[p] = make_uint4(pkmax(u0.x, u1.x), pkmax(u0.y, u1.y), pkmax(u0.z, u1.z), pkmax(u0.w, u1.w));
+            bb[p] = gb[g];
+        }
+    }
+    constexpr int DT = std::is_same<T, __bf16>::value ? KVZ_BF16 : KVZ_F16;
+    auto key = [&](const uint4& v, int i) __attribute__((always_inline)) -> float {
+        const uint32_t w = (i < 2) ? v.x : (i < 4) ? v.y : (i < 6) ? v.z : v.w;
+        return half_bits_to_float((i & 1) ? (w >> 16) : (w & 0xFFFFu), DT);
+    };
+    float lb[8];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb[i] = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        if (p < npass && p * 64 + grow < ng) {
+            bad |= !(bb[p].x == bb[p].x);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lb[i] = fmaxf(lb[i], key(uu[p], i) + bb[p].y);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_part[grow][oct * 8 + i] = lb[i];
+    if (bad) s_poison = 1;
+    __syncthreads();
+    {
+        const int j = tid & 31, part = tid >> 5;
+        float v = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v = fmaxf(v, s_part[part * 8 + q][j]);
+        s_lb8[part][j] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v = fmaxf(v, s_lb8[q][tid]);
+        s_lb[tid] = v;
+    }
+    __syncthreads();
+    if (s_poison) {   // a row with NaN statistics poisons its KV head as the reference's amax over rows does: the NaN code, by this block
+        if (tid < 32 && kb * 32 + tid < a.m) atomicMin(a.log_out + (int64_t)h * a.log_head_stride + kb * 32 + tid, 0u);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb[i] = s_lb[oct * 8 + i];
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        if (p < npass) {   // (uniform: the four threads of a group take part in the shuffles)
+            const int g = p * 64 + grow;
+            uint32_t hits = 0;
+            if (g < ng) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ub1 = key(uu[p], i) + bb[p].x;
+                    if ((kb * 32 + oct * 8 + i < a.m) && (!(ub1 < lb[i]) || a.all_pairs)) hits |= 1u << i;
+                }
+            }
+            // the group's (up to 32) candidate keys of this block go to its list behind ONE atomic: counts of the four threads, prefix in the quad
+            const int c = __builtin_popcount(hits);
+            const int l = tid & 63, q0 = l & ~3;
+            const int c0 = __shfl(c, q0, 64), c1 = __shfl(c, q0 + 1, 64), c2 = __shfl(c, q0 + 2, 64), c3 = __shfl(c, q0 + 3, 64);
+            const int tot = c0 + c1 + c2 + c3;
+            const int before = (oct > 0 ? c0 : 0) + (oct > 1 ? c1 : 0) + (oct > 2 ? c2 : 0);
+            const int64_t gi = (int64_t)h * ng + min(g, ng - 1);
+            uint32_t base = 0;
+            if (oct == 0 && tot) base = atomicAdd(a.gcount + gi, (uint32_t)tot);
+            base = (uint32_t)__shfl((int)base, q0, 64);
+            if (tot) {
+                uint32_t pos = base + (uint32_t)before;
+                uint32_t* const dst = a.klist + gi * a.kcap;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (hits & (1u << i)) dst[pos++] = (uint32_t)(kb * 32 + oct * 8 + i);
+                // a list is consumed in chunks of 32 keys: whoever got the position that OPENS a chunk announces it as a work item
+                if (oct == 0) {
+                    for (uint32_t k = (base + 31u) >> 5; (k << 5) < base + (uint32_t)tot; ++k)
+                        s_list[atomicAdd(&s_n, 1)] = (uint32_t)g | (k << 11) | ((uint32_t)h << 25);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) s_base = (int)atomicAdd(a.counter + h, (uint32_t)s_n);
+    __syncthreads();
+    uint32_t* const eh = a.entries + (int64_t)h * a.nkb * a.n_groups;
+    for (int i = tid; i < s_n; i += BD2_THREADS) eh[s_base + i] = s_list[i];
+}
+
+// The work items - (KV head, row group, chunk of 32 candidate keys), announced by score_bounds3_kernel in per-head queues - are cut into equal
+// shares, one per wave (the blocks of one XCD take one contiguous eighth, as in the pair-level kernel).  Per item: the group's 32 query rows
+// are staged into the wave's LDS buffer (LDS-DMA, swizzled like a key tile) and read into registers as the A operand; the chunk's keys are
+// gathered as the B operand - lane (j, half) loads the eight 16-byte chunks of ITS key row straight from the cache - and one chain of MFMAs
+// gives every lane the logits of its key against 16 of the rows; rounding chain, x + n_r, maximum over the lane's rows, the two halves
+// merged, one atomic minimum per key on the log-score patterns (the merge of the dense pass).  The next item's candidate indices are
+// requested while the current one is computed.
+constexpr int SK_WAVES = 4;
+#ifndef KVZ_SK_BLOCKS_PER_CU
+#define KVZ_SK_BLOCKS_PER_CU 4
+#endif
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(ScoreArgs a) {
+    typedef ScoreCfg<D> C;
+    typedef typename Mfma32<T>::v8 v8;
+    constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a group, swizzled like a key tile
+    constexpr int PB_BYTES = QG_BYTES + 256;         // + their 32 statistics n_r (written twice: one 64-lane dword DMA)
+    __shared__ __attribute__((aligned(16))) char lds[SK_WAVES * PB_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int R = a.G * a.q_len;
+    const int ng = a.n_groups;
+    const uint32_t cnt_l = (lane < a.n_kv_heads) ? a.counter[lane] : 0u;   // (Hkv < 128: lanes 0..63 hold heads 0..63, the second word below)
+    const uint32_t cnt_h = (lane + 64 < a.n_kv_heads) ? a.counter[lane + 64] : 0u;
+    auto head_count = [&](int hh) __attribute__((always_inline)) -> int {
+        return hh < 64 ? __builtin_amdgcn_readlane((int)cnt_l, hh) : __builtin_amdgcn_readlane((int)cnt_h, hh - 64);
+    };
+    int total = 0;
+    for (int hh = 0; hh < a.n_kv_heads; ++hh) total += head_count(hh);
+    const int nb8 = (int)gridDim.x >> 3;
+    const int lb = (nb8 > 0 && (gridDim.x & 7u) == 0) ? (int)(blockIdx.x & 7u) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int W = gridDim.x * SK_WAVES, w = lb * SK_WAVES + wave;
+    const int per = (total + W - 1) / W;
+    const int lo = w * per, hi = min(total, lo + per);
+    if (lo >= hi) return;
+    const int64_t head_cap = (int64_t)a.nkb * ng;
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    char* const wl = lds + wave * PB_BYTES;
+    const uint32_t wl0 = lds_addr(wl);
+    FragAddr<D> fa0;
+    fa0.init(wl, l31, half);
+    const uint32_t nb0 = wl0 + (uint32_t)QG_BYTES + (uint32_t)(4 * half) * 4u;   // + 32 qd: the statistics of accumulators 4 qd .. 4 qd + 3
+    constexpr int ROWS_PER_INSTR = 1024 / C::ROW_BYTES;
+    const int lrow = lane / C::CPR, pch = lane % C::CPR;
+    const int64_t hs = a.q_head_stride * 2;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f4v* lds_f4_t;
+    // candidate index of this lane in item e (clamped to the chunk's last one: the lanes behind it repeat it and do not store)
+    auto cand = [&](uint32_t e, int& nvalid) __attribute__((always_inline)) -> uint32_t {
+        const int g = (int)(e & 2047u), k = (int)((e >> 11) & 0x3FFFu), h = (int)(e >> 25);
+        const int64_t gi = (int64_t)h * ng + g;
+        const int n = min((int)__builtin_amdgcn_readfirstlane((int)a.gcount[gi]), a.kcap);
+        nvalid = min(32, n - k * 32);
+        return a.klist[gi * a.kcap + k * 32 + min(l31, nvalid - 1)];
+    };
+    int hcur = 0, hbase = 0;   // head of position b0, global position of its first item
+    for (int b0 = lo; b0 < hi;) {
+        while (b0 >= hbase + head_count(hcur)) { hbase += head_count(hcur); ++hcur; }
+        const int nb = min(min(64, hi - b0), hbase + head_count(hcur) - b0);   // (a batch lies inside one head's queue)
+        const uint32_t ev = a.entries[hcur * head_cap + (b0 - hbase) + min(lane, nb - 1)];
+        auto entry = [&](int i) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ev, i); };
+        int nv_next = 0;
+        uint32_t j_next = cand(entry(0), nv_next);
+        for (int i = 0; i < nb; ++i) {
+            const uint32_t e = entry(i);
+            const int g = (int)(e & 2047u), h = (int)(e >> 25);
+            const uint32_t j = j_next;
+            const int nv = nv_next;
+            {   // rows and statistics of group g -> the wave's LDS buffer (nothing through registers)
+                const char* qh = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * hs;
+                const int rc0 = min(g * 32, R - 1);
+                const int g0 = a.dq.div(rc0), qi0 = rc0 - g0 * a.q_len;   // (wave-uniform; q_len >= 32: at most two query heads per group)
+                const uint32_t base = (uint32_t)(g0 * (int)hs + qi0 * C::ROW_BYTES);
+                const uint32_t wrapd = (uint32_t)((int)hs - a.q_len * C::ROW_BYTES);
+                const int nfirst = a.q_len - qi0, tail = R - 1 - rc0;
+#pragma unroll
+                for (int r = 0; r < 32 / ROWS_PER_INSTR; ++r) {
+                    const int row = r * ROWS_PER_INSTR + lrow;
+                    const int chunk = (D == 128) ? (pch ^ (row & 15)) : (pch ^ ((row >> 1) & 7));
+                    const int rowc = min(row, tail);
+                    const uint32_t voff = base + (uint32_t)(rowc * C::ROW_BYTES + chunk * 16) + (rowc >= nfirst ? wrapd : 0u);
+                    lds_dma16a(qh, voff, wl0 + (uint32_t)(r * 1024));
+                }
+                const char* np = reinterpret_cast<const char*>(a.nrow + ((int64_t)h * ng + g) * 32);
+                const uint32_t la = __builtin_amdgcn_readfirstlane(wl0 + (uint32_t)QG_BYTES);
+                const uint64_t bs = (uint64_t)(uintptr_t)np;
+                const uint64_t bss = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bs >> 32)) << 32) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bs);
+                const uint32_t voff = (uint32_t)(l31 * 4);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(bss), "s"(la) : "memory");
+            }
+            u32x4 bk[C::KK];
+            {
+                const char* kp = reinterpret_cast<const char*>(a.k) + ((int64_t)h * a.k_head_stride + (int64_t)(a.start + (int64_t)j) * D) * 2 + half * 16;
+#pragma unroll
+                for (int kk = 0; kk < C::KK; ++kk) bk[kk] = *reinterpret_cast<const u32x4*>(kp + kk * 32);
+            }
+            if (i + 1 < nb) j_next = cand(entry(i + 1), nv_next);   // (in flight behind this item's loads)
+            stage_wait();
+            u32x4 fq[C::KK];
+            frag_load<D>(fq, fa0, 0);
+            f4v nn[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) nn[qd] = *(lds_f4_t)(uintptr_t)(nb0 + (uint32_t)(32 * qd));
+            f16v acc = zero16;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) acc = Mfma32<T>::mfma(__builtin_bit_cast(v8, fq[kk]), __builtin_bit_cast(v8, bk[kk]), acc);
+            // (wait states between the last MFMA of the chain and the assembly block that reads its result: the compiler does not count them)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            float best = -INFINITY;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint32_t xa, xb;
+                quad_round<T, FAST>(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3], xa, xb, a.c, a.rcp);
+                float t[4];   // accumulators 4 qd .. 4 qd + 3 are rows 8 qd + 4 half + (0..3)
+                quad_addn<T>(xa, xb, nn[qd].x, nn[qd].y, nn[qd].z, nn[qd].w, t);
+                best = fmaxf(fmaxf(best, t[0]), t[1]);
+                best = fmaxf(fmaxf(best, t[2]), t[3]);
+            }
+            const uint32_t bb = __builtin_bit_cast(uint32_t, best);
+            const auto sw = __builtin_amdgcn_permlane32_swap(bb, bb, false, false);
+            const float b = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+            if (half == 0 && l31 < nv) {
+                const uint32_t enc = (b >= 0.f) ? 1u : __builtin_bit_cast(uint32_t, b);   // (the encoding of the dense pass; NaN cannot come here)
+                atomicMin(a.log_out + (int64_t)h * a.log_head_stride + j, enc);
+            }
+        }
+        b0 += nb;
+    }
 }
 
 template <typename T>
@@ -2722,6 +3030,22 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         }
         if (prune >= 3) {
             a.all_pairs = (prune == 4);
+            if (prune != 5) {   // candidates at key granularity (round 6)
+                {
+                    ProfScope ps("score_bounds", stream);
+                    hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_merge_kernel");
+                    hipLaunchKernelGGL((score_bounds3_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_bounds3_kernel");
+                }
+                {
+                    ProfScope ps("score_colmax", stream);
+                    // (four blocks = sixteen waves per CU: an item is mostly latency - queue entry, candidate index, key row - and there are ~1.6 per (head, group))
+                    hipLaunchKernelGGL((score_colmax_keys_kernel<T, D, FAST>), dim3(KVZ_SK_BLOCKS_PER_CU * device_cus()), dim3(SK_WAVES * 64), 0, stream, a);
+                    KVZ_CHECK_LAUNCH("score_colmax_keys_kernel");
+                }
+                return KVZ_OK;
+            }
             {
                 ProfScope ps("score_bounds", stream);
                 hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
@@ -2731,7 +3055,7 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
             }
             {
                 ProfScope ps("score_colmax", stream);
-                hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST>), dim3(2 * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
+                hipLaunchKernelGGL((score_colmax_sparse_kernel<T, D, FAST, KVZ_SB_NBUF>), dim3((KVZ_SB_NBUF == 1 ? KVZ_SB_OCC1 : 2) * device_cus()), dim3(SB_WAVES * 64), 0, stream, a);
                 KVZ_CHECK_LAUNCH("score_colmax_sparse_kernel");
             }
             return KVZ_OK;
@@ -2787,12 +3111,16 @@ static inline size_t score_nrow_bytes(int Hkv, int G, int q_len) { return align2
 static inline size_t score_entries_bytes(int Hkv, int G, int q_len, int m) {
     return align256(((size_t)Hkv * ((m + 31) / 32) * score_n_groups(G, q_len) + 128 + PLAN_MAX_BLOCKS) * sizeof(uint32_t));   // (per-head counters, redo words, entries)
 }
+// candidates at key granularity: one counter and one list of up to nkb * 32 ctx indices per (KV head, row group)
+static inline size_t score_klist_bytes(int Hkv, int G, int q_len, int m) {
+    return align256((size_t)Hkv * score_n_groups(G, q_len) * (1 + (size_t)((m + 31) / 32) * 32) * sizeof(uint32_t));
+}
 
 extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, int sink) {
     if (Hkv <= 0 || G <= 0 || q_len <= 0 || m <= 0 || sink < 0) return 0;
     return score_stats_bytes(Hkv, G, q_len, m, sink) + score_colpart_bytes(Hkv, G, q_len, m) + score_nseg_bytes(Hkv, G, q_len) +
            score_colu_bytes(Hkv, G, q_len, m) + score_gbound_bytes(Hkv, G, q_len) + score_nrow_bytes(Hkv, G, q_len) +
-           score_entries_bytes(Hkv, G, q_len, m);
+           score_entries_bytes(Hkv, G, q_len, m) + score_klist_bytes(Hkv, G, q_len, m);
 }
 
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
@@ -2899,6 +3227,9 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.nrow) + score_nrow_bytes(Hkv, G, q_len));
     a.redo = a.counter + 128;   // (one counter per KV head: Hkv < 128)
     a.entries = a.redo + PLAN_MAX_BLOCKS;
+    a.gcount = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.counter) + score_entries_bytes(Hkv, G, q_len, m));
+    a.klist = a.gcount + (size_t)Hkv * score_n_groups(G, q_len);
+    a.kcap = ((m + 31) / 32) * 32;
     a.n_groups = score_n_groups(G, q_len);
     a.all_pairs = 0;
     a.nkb = (m + 31) / 32;

@@ -165,4 +165,6 @@ def test_half_million_token_context():
     out = kv.attend(qf, kf2, vf2, info).cpu().float()
     lens = (info["k_len"].cpu() + info["k_len_offset"]).tolist()
     ref = orc.varlen_attn(qf.cpu(), kf2.view(-1, D).cpu(), vf2.view(-1, D).cpu(), info["k_start"].tolist(), lens, 1).float()
-    assert (out - ref).abs().max() <= 1e-3
+    # (the first two halfs of every V row hold its index bits - arbitrary 16-bit patterns, inf / NaN among them: output columns 0 and 1
+    # are not numbers; the V columns are independent, so every other column is checked)
+    assert (out[..., 2:] - ref[..., 2:]).abs().max() <= 1e-3

@@ -61,12 +61,18 @@ def main():
                     tt, c = C.c_double(0), C.c_int64(0); lib.kvz_prof_read(kn.encode(), C.byref(tt), C.byref(c))
                     if c.value: t[kn] = round(tt.value / c.value * 1e3, 1)
             extra = ""
-            if pr == 3:   # the candidate list sits at the end of the workspace: [counter, pad x 3, entries ...]
-                ng = (G * q_len + 255) // 256 * 8; nkb = (m + 31) // 32
-                eb = ((Hkv * nkb * ng + 128 + 256) * 4 + 255) // 256 * 256
-                cnt = int(ws[need - eb:need - eb + 4 * Hkv].view(torch.int32).sum())
-                extra = f"  candidates {cnt} of {Hkv * nkb * ng} ({100.0 * cnt / (Hkv * nkb * ng):.1f} %)"
-                if os.environ.get("PRUNE_DEBUG"):
+            ng = (G * q_len + 255) // 256 * 8; nkb = (m + 31) // 32
+            eb = ((Hkv * nkb * ng + 128 + 256) * 4 + 255) // 256 * 256       # per-head counters, redo words, pair entries
+            kb_ = (Hkv * ng * (1 + nkb * 32) * 4 + 255) // 256 * 256          # per-group counters + key lists (round 6), behind them
+            if pr == 5:   # pair-level candidates: [counter per head, ..., entries]
+                cnt = int(ws[need - kb_ - eb:need - kb_ - eb + 4 * Hkv].view(torch.int32).sum())
+                extra = f"  candidate pairs {cnt} of {Hkv * nkb * ng} ({100.0 * cnt / (Hkv * nkb * ng):.1f} %)"
+            if pr in (3, 4):   # key-level candidates: one counter per (head, row group)
+                gc = ws[need - kb_:need - kb_ + 4 * Hkv * ng].view(torch.int32)
+                extra = (f"  candidate (group, key) items {int(gc.sum())} = {float(gc.sum()) / (Hkv * m):.2f} per key, {float(gc.float().mean()):.1f} per group (max {int(gc.max())}); "
+                         f"32x32 blocks {int(((gc + 31) // 32).sum())} (pair level: {Hkv * nkb * ng} pairs in all)")
+            if False:
+                if os.environ.get("PRUNE_DEBUG_OLD_LAYOUT"):
                     nb = (Hkv * ng * 32 * 4 + 255) // 256 * 256
                     nrow = ws[need - eb - nb:need - eb].view(torch.float32)[:Hkv * ng * 32].view(Hkv, ng * 32)
                     R = G * q_len
