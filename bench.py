@@ -77,7 +77,7 @@ def parse(argv=None):
                          "reduction through it (a 1-GPU box then exercises the collective path of the 8-GPU run)")
     ap.add_argument("--score-streams", type=int, default=0,
                     help="side streams over which the scoring calls of consecutive layers are issued (0 = the library's choice: three with "
-                         "the pruned fp16 call, two otherwise; 1 = caller's stream)")
+                         "the pruned call, two otherwise; 1 = caller's stream)")
     args = ap.parse_args(argv)
     if args.ratio is None:
         args.ratio = 0.6 if args.level == "head" else 0.3
@@ -658,6 +658,8 @@ def _run(args):
         avg_flops_a, avg_flops_b = flops_lc[0], flops_b[0]   # the bracketed launches are calls of the first chunk (q = m + 13)
         a_tf, a_ms, a_n = stage("score_rowstat", avg_flops_a, 1e12)
         b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
+        if b_ms is None:   # (measurement-only knob values that leave the column-maximum launch out: tools/r6_ab7.sh)
+            b_tf, b_ms = 0.0, 0.0
         # the pruned call (fp16 default, knob score_prune): two small launches between the passes - merged statistics + group bounds,
         # candidate pairs - and a column-maximum pass that recomputes the candidate pairs only (its flops are NOT the full ctx-column flops)
         pruned = prof.get("score_bounds", (0.0, 0))[1] > 0

@@ -2715,13 +2715,17 @@ __global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(Sco
     const int64_t hs = a.q_head_stride * 2;
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4v* lds_f4_t;
-    // candidate index of this lane in item e (clamped to the chunk's last one: the lanes behind it repeat it and do not store)
+    // candidate index of this lane in item e and the number of candidates the chunk holds: the list slot is read WITHOUT knowing the list's
+    // length (the two loads travel together: one round trip, not two); the lanes behind the end of the list take the chunk's first
+    // candidate (computing a pair twice changes nothing) and do not store
     auto cand = [&](uint32_t e, int& nvalid) __attribute__((always_inline)) -> uint32_t {
         const int g = (int)(e & 2047u), k = (int)((e >> 11) & 0x3FFFu), h = (int)(e >> 25);
         const int64_t gi = (int64_t)h * ng + g;
+        const uint32_t jraw = a.klist[gi * a.kcap + k * 32 + l31];
         const int n = min((int)__builtin_amdgcn_readfirstlane((int)a.gcount[gi]), a.kcap);
         nvalid = min(32, n - k * 32);
-        return a.klist[gi * a.kcap + k * 32 + min(l31, nvalid - 1)];
+        const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jraw);   // (slot k * 32: written by whoever opened the chunk)
+        return min(l31 < nvalid ? jraw : j0, (uint32_t)(a.m - 1));
     };
     int hcur = 0, hbase = 0;   // head of position b0, global position of its first item
     for (int b0 = lo; b0 < hi;) {
@@ -3031,14 +3035,16 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
         if (prune >= 3) {
             a.all_pairs = (prune == 4);
             if (prune != 5) {   // candidates at key granularity (round 6)
+                // (measurement only, results unusable: score_prune = 16 + mask leaves launches out - 1: the merge, 2: the bounds, 4: the candidate-key pass)
+                const int skip = prune >= 16 ? (prune & 7) : 0;
                 {
                     ProfScope ps("score_bounds", stream);
-                    hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
+                    if (!(skip & 1)) hipLaunchKernelGGL(score_merge_kernel, dim3((a.G * a.q_len + PA_ROWS - 1) / PA_ROWS * Hkv), dim3(PA_ROWS), 0, stream, a);
                     KVZ_CHECK_LAUNCH("score_merge_kernel");
-                    hipLaunchKernelGGL((score_bounds3_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
+                    if (!(skip & 2)) hipLaunchKernelGGL((score_bounds3_kernel<T>), dim3(a.nkb, Hkv), dim3(BD2_THREADS), 0, stream, a);
                     KVZ_CHECK_LAUNCH("score_bounds3_kernel");
                 }
-                {
+                if (!(skip & 4)) {
                     ProfScope ps("score_colmax", stream);
                     // (four blocks = sixteen waves per CU: an item is mostly latency - queue entry, candidate index, key row - and there are ~1.6 per (head, group))
                     hipLaunchKernelGGL((score_colmax_keys_kernel<T, D, FAST>), dim3(KVZ_SK_BLOCKS_PER_CU * device_cus()), dim3(SK_WAVES * 64), 0, stream, a);
