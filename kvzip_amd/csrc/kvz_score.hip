@@ -2561,7 +2561,7 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
     const int npass = (ng + 63) / 64;
     const uint4* ub = reinterpret_cast<const uint4*>(a.colu + ((int64_t)(h * a.nkb + kb) * ng) * 64);   // per group: 8 uint4 (two halves of 32 keys)
     const float2* gb = a.gbound + (int64_t)h * ng;
-    uint4 uu[BD2_MAXPASS];
+    float kf[BD2_MAXPASS][8];   // the thread's 8 bounds u of every pass as fp32: converted once, read by both phases below
     float2 bb[BD2_MAXPASS];
 #pragma unroll
     for (int p = 0; p < BD2_MAXPASS; ++p) {
@@ -2578,15 +2578,12 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
                 }
                 return r;
             };
-            uu[p] = make_uint4(pkmax(u0.x, u1.x), pkmax(u0.y, u1.y), pkmax(u0.z, u1.z), pkmax(u0.w, u1.w));
+            const uint32_t w0 = pkmax(u0.x, u1.x), w1 = pkmax(u0.y, u1.y), w2 = pkmax(u0.z, u1.z), w3 = pkmax(u0.w, u1.w);
+            kf[p][0] = pair_lo<T>(w0); kf[p][1] = pair_hi<T>(w0); kf[p][2] = pair_lo<T>(w1); kf[p][3] = pair_hi<T>(w1);
+            kf[p][4] = pair_lo<T>(w2); kf[p][5] = pair_hi<T>(w2); kf[p][6] = pair_lo<T>(w3); kf[p][7] = pair_hi<T>(w3);
             bb[p] = gb[g];
         }
     }
-    constexpr int DT = std::is_same<T, __bf16>::value ? KVZ_BF16 : KVZ_F16;
-    auto key = [&](const uint4& v, int i) __attribute__((always_inline)) -> float {
-        const uint32_t w = (i < 2) ? v.x : (i < 4) ? v.y : (i < 6) ? v.z : v.w;
-        return half_bits_to_float((i & 1) ? (w >> 16) : (w & 0xFFFFu), DT);
-    };
     float lb[8];
     bool bad = false;
 #pragma unroll
@@ -2596,7 +2593,7 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
         if (p < npass && p * 64 + grow < ng) {
             bad |= !(bb[p].x == bb[p].x);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) lb[i] = fmaxf(lb[i], key(uu[p], i) + bb[p].y);
+            for (int i = 0; i < 8; ++i) lb[i] = fmaxf(lb[i], kf[p][i] + bb[p].y);
         }
     }
 #pragma unroll
@@ -2632,26 +2629,27 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
             if (g < ng) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float ub1 = key(uu[p], i) + bb[p].x;
+                    const float ub1 = kf[p][i] + bb[p].x;
                     if ((kb * 32 + oct * 8 + i < a.m) && (!(ub1 < lb[i]) || a.all_pairs)) hits |= 1u << i;
                 }
             }
             // the group's (up to 32) candidate keys of this block go to its list behind ONE atomic: counts of the four threads, prefix in the quad
+            // (DPP quad broadcasts: no LDS round trip; most quads have no candidate at all - one or two of the 448 groups per key)
+            if (__builtin_amdgcn_ballot_w64(hits != 0) == 0) continue;   // (wave-uniform)
             const int c = __builtin_popcount(hits);
-            const int l = tid & 63, q0 = l & ~3;
-            const int c0 = __shfl(c, q0, 64), c1 = __shfl(c, q0 + 1, 64), c2 = __shfl(c, q0 + 2, 64), c3 = __shfl(c, q0 + 3, 64);
+            auto qb = [](int v, auto sel) __attribute__((always_inline)) -> int { return __builtin_amdgcn_update_dpp(0, v, decltype(sel)::value, 0xf, 0xf, false); };
+            const int c0 = qb(c, std::integral_constant<int, 0x00>{}), c1 = qb(c, std::integral_constant<int, 0x55>{});
+            const int c2 = qb(c, std::integral_constant<int, 0xAA>{}), c3 = qb(c, std::integral_constant<int, 0xFF>{});
             const int tot = c0 + c1 + c2 + c3;
             const int before = (oct > 0 ? c0 : 0) + (oct > 1 ? c1 : 0) + (oct > 2 ? c2 : 0);
             const int64_t gi = (int64_t)h * ng + min(g, ng - 1);
             uint32_t base = 0;
             if (oct == 0 && tot) base = atomicAdd(a.gcount + gi, (uint32_t)tot);
-            base = (uint32_t)__shfl((int)base, q0, 64);
+            base = (uint32_t)qb((int)base, std::integral_constant<int, 0x00>{});
             if (tot) {
                 uint32_t pos = base + (uint32_t)before;
                 uint32_t* const dst = a.klist + gi * a.kcap;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (hits & (1u << i)) dst[pos++] = (uint32_t)(kb * 32 + oct * 8 + i);
+                for (uint32_t hb = hits; hb; hb &= hb - 1) dst[pos++] = (uint32_t)(kb * 32 + oct * 8 + __builtin_ctz(hb));
                 // a list is consumed in chunks of 32 keys: whoever got the position that OPENS a chunk announces it as a work item
                 if (oct == 0) {
                     for (uint32_t k = (base + 31u) >> 5; (k << 5) < base + (uint32_t)tot; ++k)

@@ -24,10 +24,12 @@ DEV = "cuda:0"
 # An entry can only flip where a score that is not bit-identical to the reference's sits at the threshold: with a fraction f of
 # non-identical scores (fp16 ~1e-3, bf16 ~1e-4, conftest.SCORE_BOUNDS) and T scores sharing the threshold value or the grid
 # step next to it (fp16: a few hundred of 512 000; bf16: thousands, but its non-identical scores are ten times rarer), the
-# expectation is ~ f * T <= 1 per ratio at this size.  Allowed: 8 (fp16) / 2 (bf16) per ratio on 512 000 scores; 0 on the smaller
-# fixtures.  The same arithmetic at the headline size (14.68 M scores, 28 x more): expect some tens of flipped entries in fp16,
-# a handful in bf16 - every one a last-bit difference of the fp32 accumulation order at the threshold.
-FLIPS_512K = {"f16": 8, "bf16": 2}
+# expectation is ~ f * T <= 1 per ratio at this size.  Allowed: the largest count ever measured + 1 - 3 (fp16: 1 / 2 / 1 / 0 over the four
+# ratios in round 5, 1 at ratio 0.3 in round 6) / 2 (bf16: 0 / 0 / 0 / 1, 0) per ratio on 512 000 scores; 0 on the smaller fixtures.
+# Measured on ONE FULL LAYER of the headline context against the reference (G15, tests/test_gpu_far_context.py: 524 288 scores, 483 /
+# 35 of them not bit-identical): 0 (fp16) / 1 (bf16) flipped entries - every one a last-bit difference of the fp32 accumulation order
+# at the threshold.
+FLIPS_512K = {"f16": 3, "bf16": 2}
 
 
 def _drive(kv, K0, per_chunk, geom):

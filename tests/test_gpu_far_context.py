@@ -94,7 +94,7 @@ def test_full_layer_of_the_headline_context_against_the_reference(tag):
           f"step, worst {int(d.max())}; thres {thres!r} vs reference {want_thres!r}; mask Hamming distance {ham}; kept ratio {r_real:.5f}")
     assert thres == want_thres
     # (one layer's scores share the threshold with nobody else: the count of entries AT the threshold value decides how many can flip)
-    check_mask_flips(f"g15 full layer/{tag}", got, want, kv.valid.cpu(), want_valid, want_thres, allowed=8 if tag == "f16" else 2)
+    check_mask_flips(f"g15 full layer/{tag}", got, want, kv.valid.cpu(), want_valid, want_thres, allowed=3 if tag == "f16" else 2)
     assert np.array_equal(kv.valid.cpu().sum(-1).reshape(Hkv).numpy().astype(np.int32) - g[f"{tag}/kept"],
                           (kv.valid.cpu().int() - want_valid.int()).sum(-1).reshape(Hkv).numpy())
 
