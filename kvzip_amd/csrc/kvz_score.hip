@@ -1687,7 +1687,9 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     const uint16_t* urow;            // u of the wave's group: + (kb * n_groups) * 32 + lane
     uint32_t u_spare, u_lane;        // byte offsets from urow: the spare row behind the array; the lane's part of its key's offset
     int u_c;                         // (lane & 31) - sink: ctx index of the lane's key minus k0
-    bool tile_ctx = true, tile_ctx_full = false;   // the current tile holds ctx keys / nothing but ctx keys (wave-uniform)
+    int tile_ctx = 1, tile_ctx_full = 0;   // the current tile holds ctx keys / nothing but ctx keys (scalar registers: a bool carried through
+                                           // the loop comes back as a lane mask, and the branch on it costs two vector instructions per step)
+
     auto start_item = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) lsum[k] = 0.f;   // (nm, nm_max: init_refs, behind the item's first chain)
@@ -1793,6 +1795,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
             uint32_t u16;
             if constexpr (F16) u16 = max16_bits<T>(xp);
             else u16 = __builtin_bit_cast(uint32_t, max16_f32(xf)) >> 16;
+            // (round 6: the block term of the offset moved into the scalar base of the store - four vector instructions fewer per step - is
+            // 1.7 % SLOWER in the scoring loop: 16 more scalar spills and a second branch inside the step; profiles/r6_passA_small_steps_ab.txt)
             uint32_t off = (uint32_t)((k0 >> 5) * a.n_groups * 128) + u_lane;
             if (!tile_ctx_full) off = ((uint32_t)(k0 + u_c) < (uint32_t)a.m) ? off : u_spare;   // (wave-uniform: only the tiles at the ends of the ctx range)
             asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(u16), "s"(urow) : "memory");
@@ -1914,8 +1918,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         constexpr int B1 = (B + 1) % RING;
         typedef std::integral_constant<int, B1> IB1;
         const int k0 = t * SC_TILE;
-        tile_ctx = k0 < a.sink + a.m && k0 + SC_TILE > a.sink;
-        tile_ctx_full = k0 >= a.sink && k0 + SC_TILE <= a.sink + a.m;
+        tile_ctx = __builtin_amdgcn_readfirstlane((k0 < a.sink + a.m && k0 + SC_TILE > a.sink) ? 1 : 0);
+        tile_ctx_full = __builtin_amdgcn_readfirstlane((k0 >= a.sink && k0 + SC_TILE <= a.sink + a.m) ? 1 : 0);
         const bool young = wave >= NWAVES / 2;
         auto nohook = [&]() __attribute__((always_inline)) {};
         // a tile that holds a causal limit of the wave's rows (round 6): only the 32-key blocks that CUT the rows pay for the masks (the
