@@ -612,7 +612,7 @@ def _run(args):
     pmc = {}
     try:
         if args.model == "qwen2.5-7b" and N == 131072 and abs(ratio - 0.3) < 1e-9 and not head_level:
-            for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(path):
                     pmc = json.load(open(path))
@@ -660,7 +660,7 @@ def _run(args):
         b_tf, b_ms, b_n = stage("score_colmax", avg_flops_b, 1e12)
         if b_ms is None:   # (measurement-only knob values that leave the column-maximum launch out: tools/r6_ab7.sh)
             b_tf, b_ms = 0.0, 0.0
-        # the pruned call (fp16 default, knob score_prune): two small launches between the passes - merged statistics + group bounds,
+        # the pruned call (default for both dtypes, knob score_prune): two small launches between the passes - merged statistics + group bounds,
         # candidate pairs - and a column-maximum pass that recomputes the candidate pairs only (its flops are NOT the full ctx-column flops)
         pruned = prof.get("score_bounds", (0.0, 0))[1] > 0
         m_ms = (prof["score_bounds"][0] / prof["score_bounds"][1]) if pruned else 0.0
@@ -673,7 +673,7 @@ def _run(args):
                               "note": "pass A alone, credited with ALL of the call's 8(d) flops (the convention of rounds 1-4)"},
             "score_colmax": {"bound": "mfma", "achieved": None if pruned else b_tf, "unit": "TFLOP/s", "frac": None if pruned else b_tf / MFMA_PEAK_TFLOPS,
                              "avg_ms": b_ms, "launches": b_n,
-                             "note": ("sparse pass B: only the candidate (32-row group, 32-key block) pairs are recomputed (exact bounds from pass A)"
+                             "note": ("candidate-key pass: per 32-row group only the keys whose column maximum the group can hold are recomputed, 32 gathered keys per MFMA tile (exact bounds from pass A)"
                                       if pruned else "pass B alone over its own recomputed ctx-column flops")},
             "score_bounds": ({"avg_ms": m_ms, "launches": prof["score_bounds"][1],
                               "note": "statistics merge + group bounds, candidate pairs (two launches in one bracket)"} if pruned else None),
@@ -697,7 +697,7 @@ def _run(args):
             "unit": "TFLOP/s", "frac": score_combined_tf / MFMA_PEAK_TFLOPS,
             "avg_ms": a_ms + m_ms + b_ms, "launches": min(a_n, b_n), "pruned_call": pruned,
             "traffic": (sum((pmc.get(kn, {}).get("traffic_bytes") or 0) for kn in
-                            (("score_rowstatT2", "score_merge", "score_bounds2", "score_colmax_sparse") if pruned else ("score_rowstat", "score_colmax"))) or None),
+                            (("score_rowstatT2", "score_merge", "score_bounds3", "score_colmax_keys") if pruned else ("score_rowstat", "score_colmax"))) or None),
             "achieved_step_tflops": step_flops / (elapsed / args.steps) / 1e12,   # per GPU: 8(d) flops of one context's step / ms_per_step
             "peak_random_fp16_operands": MFMA_RANDOM_DATA_TFLOPS,
             "frac_of_peak_random_fp16_operands": score_combined_tf / MFMA_RANDOM_DATA_TFLOPS,
@@ -734,12 +734,12 @@ def _run(args):
                         "2.35 GHz rocm-smi reports - the kernels run at 1.95 GHz (power limit), where VALU + MFMA time add up to "
                         "~0.95 of the measured duration (profiles/r5_scoring_attribution.txt)"}
         sqs = pmc.get("_sq_counters", {})
-        if pruned and all(sqs.get(kn, {}).get("SQ_ACTIVE_INST_VALU") for kn in ("score_rowstatT2", "score_colmax_sparse")):
+        if pruned and all(sqs.get(kn, {}).get("SQ_ACTIVE_INST_VALU") for kn in ("score_rowstatT2", "score_colmax_keys")):
             us = lambda sq: 4.0 * sq["SQ_ACTIVE_INST_VALU"] / 1024 / (CLOCK_UNDER_SCORING_GHZ * 1e3)
             mfp = lambda sq: sq.get("SQ_INSTS_MFMA", 0) / 1024 * (32 * 32 * 16 * 2 * 1024 / (MFMA_RANDOM_DATA_TFLOPS * 1e12)) * 1e6
-            ka, kb = sqs["score_rowstatT2"], sqs["score_colmax_sparse"]
+            ka, kb = sqs["score_rowstatT2"], sqs["score_colmax_keys"]
             roofline["valu_issue_bound"] = {
-                "valu_active_us": {"rowstat": us(ka), "colmax_sparse": us(kb)}, "mfma_at_power_limit_us": {"rowstat": mfp(ka), "colmax_sparse": mfp(kb)},
+                "valu_active_us": {"rowstat": us(ka), "colmax_keys": us(kb)}, "mfma_at_power_limit_us": {"rowstat": mfp(ka), "colmax_keys": mfp(kb)},
                 "valu_plus_mfma_at_power_limit_us": us(ka) + us(kb) + mfp(ka) + mfp(kb), "measured_us": (a_ms + m_ms + b_ms) * 1e3,
                 "frac_of_valu_plus_mfma_at_power_limit": (us(ka) + us(kb) + mfp(ka) + mfp(kb)) / ((a_ms + m_ms + b_ms) * 1e3),
                 "simds": 1024, "clock_ghz_under_load": CLOCK_UNDER_SCORING_GHZ,

@@ -2625,9 +2625,14 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) lb[i] = s_lb[oct * 8 + i];
+    // two phases, so that the atomics of a thread's passes are all in flight together (one after the other, each waiting for its position,
+    // they were the longest thing in the kernel): first every pass's candidates and ONE atomic per quad of threads that has any ...
+    uint32_t hits_[BD2_MAXPASS], base_[BD2_MAXPASS];
+    auto qb = [](int v, auto sel) __attribute__((always_inline)) -> int { return __builtin_amdgcn_update_dpp(0, v, decltype(sel)::value, 0xf, 0xf, false); };
 #pragma unroll
     for (int p = 0; p < BD2_MAXPASS; ++p) {
-        if (p < npass) {   // (uniform: the four threads of a group take part in the shuffles)
+        hits_[p] = 0; base_[p] = 0;
+        if (p < npass) {   // (uniform: the four threads of a group take part in the quad broadcasts)
             const int g = p * 64 + grow;
             uint32_t hits = 0;
             if (g < ng) {
@@ -2637,22 +2642,31 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
                     if ((kb * 32 + oct * 8 + i < a.m) && (!(ub1 < lb[i]) || a.all_pairs)) hits |= 1u << i;
                 }
             }
-            // the group's (up to 32) candidate keys of this block go to its list behind ONE atomic: counts of the four threads, prefix in the quad
-            // (DPP quad broadcasts: no LDS round trip; most quads have no candidate at all - one or two of the 448 groups per key)
+            hits_[p] = hits;
+            // (most quads have no candidate at all - a key names two or three of the 448 groups)
             if (__builtin_amdgcn_ballot_w64(hits != 0) == 0) continue;   // (wave-uniform)
             const int c = __builtin_popcount(hits);
-            auto qb = [](int v, auto sel) __attribute__((always_inline)) -> int { return __builtin_amdgcn_update_dpp(0, v, decltype(sel)::value, 0xf, 0xf, false); };
+            const int tot = qb(c, std::integral_constant<int, 0x00>{}) + qb(c, std::integral_constant<int, 0x55>{}) +
+                            qb(c, std::integral_constant<int, 0xAA>{}) + qb(c, std::integral_constant<int, 0xFF>{});
+            if (oct == 0 && tot) base_[p] = atomicAdd(a.gcount + (int64_t)h * ng + min(g, ng - 1), (uint32_t)tot);
+        }
+    }
+    // ... then the group's (up to 32) candidate keys of this block go to its list behind the quad's position (prefix of the four counts)
+#pragma unroll
+    for (int p = 0; p < BD2_MAXPASS; ++p) {
+        if (p < npass) {
+            const uint32_t hits = hits_[p];
+            if (__builtin_amdgcn_ballot_w64(hits != 0) == 0) continue;   // (wave-uniform)
+            const int g = p * 64 + grow;
+            const int c = __builtin_popcount(hits);
             const int c0 = qb(c, std::integral_constant<int, 0x00>{}), c1 = qb(c, std::integral_constant<int, 0x55>{});
             const int c2 = qb(c, std::integral_constant<int, 0xAA>{}), c3 = qb(c, std::integral_constant<int, 0xFF>{});
             const int tot = c0 + c1 + c2 + c3;
             const int before = (oct > 0 ? c0 : 0) + (oct > 1 ? c1 : 0) + (oct > 2 ? c2 : 0);
-            const int64_t gi = (int64_t)h * ng + min(g, ng - 1);
-            uint32_t base = 0;
-            if (oct == 0 && tot) base = atomicAdd(a.gcount + gi, (uint32_t)tot);
-            base = (uint32_t)qb((int)base, std::integral_constant<int, 0x00>{});
+            const uint32_t base = (uint32_t)qb((int)base_[p], std::integral_constant<int, 0x00>{});
             if (tot) {
                 uint32_t pos = base + (uint32_t)before;
-                uint32_t* const dst = a.klist + gi * a.kcap;
+                uint32_t* const dst = a.klist + ((int64_t)h * ng + min(g, ng - 1)) * a.kcap;
                 for (uint32_t hb = hits; hb; hb &= hb - 1) dst[pos++] = (uint32_t)(kb * 32 + oct * 8 + __builtin_ctz(hb));
                 // a list is consumed in chunks of 32 keys: whoever got the position that OPENS a chunk announces it as a work item
                 if (oct == 0) {

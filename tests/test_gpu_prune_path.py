@@ -1,6 +1,6 @@
-"""The exact-pruning variant of the scoring call (round 5; round 6: both dtypes; knob ``score_prune``: 3 = the default, 0 = the two-pass call): a key-per-lane pass A that also writes
-per-group maxima, merged statistics + group bounds, a compacted list of candidate (32-row group, 32-key block) pairs, a sparse pass B over
-those pairs.
+"""The exact-pruning variant of the scoring call (round 5; round 6: both dtypes, candidates at key granularity; knob ``score_prune``: 3 = the default,
+0 = the two-pass call, 5 = round 5's candidate pairs): a key-per-lane pass A that also writes per-group maxima, merged statistics + group bounds, per
+row group the list of ctx keys whose column maximum the group can hold, a pass that recomputes 32 gathered candidate keys per MFMA tile.
 
 What is asserted: against the CPU oracle the same fixed bounds as the product path (``conftest.SCORE_BOUNDS``); the sparse pass B returns
 THE SAME BITS as the full pass B on the same statistics (knob 1 vs 3) and as the sparse pass over every pair (knob 4) - the bounds are
@@ -62,10 +62,11 @@ def test_pruned_scoring_call(H, Hkv, D, sink, N, start, m, q_len, dtype):
     q, k = _inputs(H, Hkv, D, sink, N, q_len, seed=H * 1000 + m, dtype=dtype)
     want = orc.get_score(q, k, sink, start, start + m)[0]
     qd, kd = q.to(DEV), k.to(DEV)
-    got = {p: _score_log(qd, kd, sink, start, start + m, p) for p in (1, 3, 4)}
+    got = {p: _score_log(qd, kd, sink, start, start + m, p) for p in (1, 3, 4, 5)}
     check_score_parity(f"prune/{H}x{Hkv}x{D}/m{m}/{dtype}", got[3], want)
-    assert _same_bits(got[3], got[1]), "sparse pass B differs from the full pass B on the same statistics"
-    assert _same_bits(got[3], got[4]), "candidate pairs differ from all pairs"
+    assert _same_bits(got[3], got[1]), "candidate-key pass differs from the full pass B on the same statistics"
+    assert _same_bits(got[3], got[4]), "candidate keys differ from all (group, key) items"
+    assert _same_bits(got[3], got[5]), "candidate keys (round 6) differ from candidate pairs (round 5)"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

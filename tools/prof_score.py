@@ -18,7 +18,7 @@ H, Hkv, D, sink, N, m = 28, 4, 128, 32, 131072, 2000
 q_len = m + 26
 klen = sink + N + q_len
 g = torch.Generator(device=dev).manual_seed(0)
-dt = torch.float16
+dt = torch.bfloat16 if os.environ.get("PROF_DTYPE") == "bf16" else torch.float16
 if what == "score":
     q = torch.randn(1, H, q_len, D, generator=g, device=dev).to(dt)
     k = torch.randn(1, Hkv, klen, D, generator=g, device=dev).to(dt)
