@@ -354,6 +354,10 @@ constexpr int PLAN_MAX_BLOCKS = 256;
 struct PaPlan {
     uint16_t unit[PLAN_MAX_BLOCKS + 1];  // block b starts at key tile tile[b] of unit unit[b] and ends where block b+1 starts
     uint16_t tile[PLAN_MAX_BLOCKS + 1];
+    uint16_t perm[PLAN_MAX_BLOCKS];      // hardware block -> range of the partition (round 6, key-per-lane kernel): workgroup b runs on XCD b % 8 and every
+                                         // XCD has its own L2, so the ranges are dealt head by head - the ~32 blocks of an XCD then stream the key tiles
+                                         // of ONE KV head (two XCDs per head at Hkv = 4) instead of every head's, and the fabric carries each head's
+                                         // keys to two L2s, not eight
     int nb;                              // blocks
     int max_seg;                         // most blocks that touch one unit (= partial statistics per row)
 };
@@ -440,6 +444,17 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
         if (run > best) best = run;
     }
     p.max_seg = best;
+    // hardware block -> range: ranges sorted by the KV head of their first unit (stable), the sorted list dealt to the XCDs in contiguous eighths
+    for (int b = 0; b < PLAN_MAX_BLOCKS; ++b) p.perm[b] = (uint16_t)b;
+    if (p.nb % 8 == 0 && Hkv > 1) {
+        uint16_t sorted[PLAN_MAX_BLOCKS];
+        int n = 0;
+        for (int h = 0; h < Hkv; ++h)
+            for (int b = 0; b < p.nb; ++b)
+                if ((int)(p.unit[b] % (unsigned)Hkv) == h) sorted[n++] = (uint16_t)b;
+        if (n == p.nb)
+            for (int b = 0; b < p.nb; ++b) p.perm[b] = sorted[(b % 8) * (p.nb / 8) + b / 8];
+    }
     return true;
 }
 
@@ -1482,12 +1497,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
 
     struct Item { int k, h, rt, z, t_lo, t_hi; };  // unit, KV head, row tile, ordinal of the partial, key tiles [t_lo, t_hi)
     // exactly balanced static partition (PaPlan): this block's range of the tile sequence, walked as segments; Item.k = unit
-    const int u_first = plan.unit[blockIdx.x], t_first = plan.tile[blockIdx.x];
-    const int u_end = plan.unit[blockIdx.x + 1], t_end = plan.tile[blockIdx.x + 1];  // exclusive: (u_end, t_end)
+    const int pb = plan.perm[blockIdx.x];   // this block's range of the partition (dealt head by head over the XCDs: see PaPlan)
+    const int u_first = plan.unit[pb], t_first = plan.tile[pb];
+    const int u_end = plan.unit[pb + 1], t_end = plan.tile[pb + 1];  // exclusive: (u_end, t_end)
     int ord0 = 0;  // ordinal of the first segment inside its unit = earlier blocks that also started inside it (+ the opener)
     if (t_first > 0) {
         ord0 = 1;
-        for (int bb = (int)blockIdx.x - 1; bb > 0 && plan.unit[bb] == u_first && plan.tile[bb] > 0; --bb) ++ord0;
+        for (int bb = pb - 1; bb > 0 && plan.unit[bb] == u_first && plan.tile[bb] > 0; --bb) ++ord0;
     }
     auto item_from = [&](int u) -> Item {
         Item it;
