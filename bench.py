@@ -692,7 +692,7 @@ def _run(args):
                                                 "bracketed durations"}
         # Round 5: the headline roofline is the scoring STAGE - both launches of a (layer, chunk) call - not pass A alone
         roofline = {
-            "bound": "mfma", "kernel": "score (rowstat + bounds + sparse colmax)" if pruned else "score (rowstat + colmax)",
+            "bound": "mfma", "kernel": "score (rowstat + merge + bounds + candidate-key colmax)" if pruned else "score (rowstat + colmax)",
             "achieved": score_combined_tf, "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": score_combined_tf / MFMA_PEAK_TFLOPS,
             "avg_ms": a_ms + m_ms + b_ms, "launches": min(a_n, b_n), "pruned_call": pruned,
@@ -702,7 +702,7 @@ def _run(args):
             "peak_random_fp16_operands": MFMA_RANDOM_DATA_TFLOPS,
             "frac_of_peak_random_fp16_operands": score_combined_tf / MFMA_RANDOM_DATA_TFLOPS,
             "note": ("the scoring stage: algorithmic flops = 2*H*D*q*(sink+m+q) per (layer,chunk) call (QK^T only, SURVEY §8d) over the "
-                     "time of ALL launches of the call (pass A rowstat [+ merge / bounds + candidate pairs] + pass B colmax; per launch: roofline_stages); achieved_step_tflops = the "
+                     "time of ALL launches of the call (pass A rowstat [+ merge / bounds + candidate keys] + pass B colmax; per launch: roofline_stages); achieved_step_tflops = the "
                      "same flops of a whole step over ms_per_step (side streams, selection and compaction included); kernel durations "
                      f"from hipEvents on the launch stream inside the timed region: the first {n_prof} scoring calls of every step (first "
                      "chunk, q = m + 13) run alone on the caller's stream and are bracketed (the GPU is idle at a step's start: no "

@@ -23,8 +23,10 @@ int kvz_debug_fastdiv(int d, int n, int* quotient, int* remainder);
 /* test / tuning hook: set a tuning knob of the library ("attn_items", "flash_min_rows", "flash2_min_blocks", "flash2_xcd", "flash2_split",
  * "sel_blocks", "emit_blocks", "score_prune"; value <= 0 restores the default - the on / off knobs flash2_xcd, flash2_split and score_prune
  * take 0 as "off" and negative values as "default") and return its previous value (< 0: unknown name).
- * "score_prune" (fp16, deferred-log entry points): 3 (default) = key-per-lane row statistics + candidate pairs + sparse column maxima,
- * 0 = two full passes over Q.K^T, 1 / 4 = check variants (kvz_score.hip); KVZIP_SCORE_PRUNE in the environment presets it.
+ * "score_prune" (both dtypes, deferred-log entry points, chunks of >= 32 query positions): 3 (default) = key-per-lane row statistics +
+ * candidate keys per row group + gathered column maxima, 5 = candidate (group, key block) pairs (round 5), 0 = two full passes over Q.K^T,
+ * 1 / 4 = check variants, 16 + mask = launches left out (time measurements only, results unusable) (kvz_score.hip); KVZIP_SCORE_PRUNE in the
+ * environment presets it.
  * Process-wide, not thread-safe: for tests and probes.  kvz_debug_get_tunable: the current value. */
 int kvz_debug_set_tunable(const char* name, int value);
 int kvz_debug_get_tunable(const char* name);

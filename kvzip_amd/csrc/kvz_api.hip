@@ -102,8 +102,9 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 //   one per CU, device_cus(): every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
 // score_prune (both dtypes, deferred-log entry points, chunks of >= 32 query positions; everything else takes the two full passes whatever the knob says): 3 (default) = key-per-lane
-//   row statistics + candidate pairs + sparse column maxima (kvz_score.hip, round 5); 0 = two full passes over Q.K^T; 1 / 4 = check variants
-//   (key-per-lane statistics with the full column-maximum pass / every pair through the sparse pass).  KVZIP_SCORE_PRUNE presets it.
+//   row statistics + candidate keys per row group + gathered column maxima (kvz_score.hip, round 6); 5 = candidate (group, key block) pairs (round 5); 0 = two full passes over
+//   Q.K^T; 1 / 4 = check variants (key-per-lane statistics with the full column-maximum pass / every (group, key) item through the candidate pass); 16 + mask: launches left out
+//   (time measurements only).  KVZIP_SCORE_PRUNE presets it.
 static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 3};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
 static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {3}};   // (atomic: a probe may flip a knob while another thread launches)
 // (KVZIP_SCORE_PRUNE in the environment presets the score_prune knob when the library is loaded: A/B runs of whole programs)

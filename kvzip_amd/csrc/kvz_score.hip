@@ -446,7 +446,10 @@ static bool make_plan(PaPlan& p, int rows, int sink, int m, int q_len, int G, in
     p.max_seg = best;
     // hardware block -> range: ranges sorted by the KV head of their first unit (stable), the sorted list dealt to the XCDs in contiguous eighths
     for (int b = 0; b < PLAN_MAX_BLOCKS; ++b) p.perm[b] = (uint16_t)b;
-    if (p.nb % 8 == 0 && Hkv > 1) {
+#ifndef KVZ_PLAN_PERM
+#define KVZ_PLAN_PERM 1
+#endif
+    if (KVZ_PLAN_PERM && p.nb % 8 == 0 && Hkv > 1) {
         uint16_t sorted[PLAN_MAX_BLOCKS];
         int n = 0;
         for (int h = 0; h < Hkv; ++h)
