@@ -661,7 +661,7 @@ def _run(args):
         if b_ms is None:   # (measurement-only knob values that leave the column-maximum launch out: tools/r6_ab7.sh)
             b_tf, b_ms = 0.0, 0.0
         # the pruned call (default for both dtypes, knob score_prune): two small launches between the passes - merged statistics + group bounds,
-        # candidate pairs - and a column-maximum pass that recomputes the candidate pairs only (its flops are NOT the full ctx-column flops)
+        # candidate keys per row group - and a column-maximum pass that recomputes the candidates only (its flops are NOT the full ctx-column flops)
         pruned = prof.get("score_bounds", (0.0, 0))[1] > 0
         m_ms = (prof["score_bounds"][0] / prof["score_bounds"][1]) if pruned else 0.0
         s_gbs, s_ms, s_n = stage("select", 5.0 * L * Hkv * N, 1e9)
@@ -676,7 +676,7 @@ def _run(args):
                              "note": ("candidate-key pass: per 32-row group only the keys whose column maximum the group can hold are recomputed, 32 gathered keys per MFMA tile (exact bounds from pass A)"
                                       if pruned else "pass B alone over its own recomputed ctx-column flops")},
             "score_bounds": ({"avg_ms": m_ms, "launches": prof["score_bounds"][1],
-                              "note": "statistics merge + group bounds, candidate pairs (two launches in one bracket)"} if pruned else None),
+                              "note": "statistics merge + group bounds, candidate keys per row group (two launches in one bracket)"} if pruned else None),
             "score_combined": {"bound": "mfma", "achieved": score_combined_tf, "unit": "TFLOP/s",
                                "frac": score_combined_tf / MFMA_PEAK_TFLOPS},
             "select": {"bound": "hbm", "achieved": s_gbs, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS, "avg_ms": s_ms,
