@@ -1759,7 +1759,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
     auto step = [&](f16v& accn, const f16v& accc, int k0, auto s_tag, auto mask_tag, auto lb_tag, auto lkb_tag, auto&& hook) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_tag)::value;
         uint32_t xp[8];
-        const int kv = k0 + l31;   // this lane's key
         // (MASK) bit c of vism <=> the row with c_k = c sees this lane's key: [mask_a, mask_w) and [mask_b, 32)
         uint32_t vism = 0xFFFFFFFFu;
         if (MASK) {
@@ -1909,7 +1908,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         refw = (r == -INFINITY) ? 0.f : r;
         nmw = -(refw * L2E);
     };
-    bool next_ready = false;
     // Hand-over in the third step of a tile (B = its buffer).  Every fragment of the tile has been read by now (block 3 in the
     // second step).  With three buffers the tile two positions ahead goes into the buffer that the PREVIOUS hand-over freed,
     // so its DMA is issued BEFORE the barrier: a wave that arrives early issues while the others still compute, and after
@@ -1930,7 +1928,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // the next tile (and older pieces) landed
         else stage_wait();
         block_barrier();  // ... everybody's part has, and nobody reads tile B any more
-        next_ready = staged >= sp + 2;
     };
     auto tile_steps = [&](auto b_tag, auto mask_tag) __attribute__((always_inline)) {
         constexpr int B = decltype(b_tag)::value;
@@ -2014,7 +2011,6 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
         if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else stage_wait();
         block_barrier();
-        next_ready = staged >= sp + 2;
     };
     (void)diag0;
 
