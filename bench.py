@@ -771,6 +771,8 @@ def _run(args):
             "host_enqueue_ms_per_step": host_issue / args.steps * 1e3,   # (GPU-bound run: includes the time the host is throttled by full queues)
             "host_us_per_update_score_pair": (timing["pair_s"] / timing["pairs"] * 1e6) if timing.get("pairs") else None,
             "update_score_fused": not args.unfused_update,
+            "score_prune": lib.kvz_debug_get_tunable(b"score_prune"),   # 6: the tail of the pruned call pipelined over the calls of a side stream (one launch
+                                                                        # per call instead of three); the bracketed calls of roofline_stages run the chained form (3)
             "hbm_copy_GBps_this_box": copy_gbs,   # 1-GiB device-to-device copy (read + write), same process: the box's own HBM ceiling
             "tune": args.tune,
         },

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KVZ_ABI_VERSION 5
+#define KVZ_ABI_VERSION 6
 
 /* element type of K/V/Q/score tensors (reference: csrc/csrc/static_switch.h:3-12) */
 #define KVZ_F16 0
@@ -144,6 +144,19 @@ int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_st
                                const void* q, int64_t q_head_stride, int sink, int start, int end, int q_len,
                                int Hkv, int G, int D, int dtype,
                                uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes);
+
+/* Pipelined tail of the asynchronous log calls (knob score_prune = 6; no reference counterpart - the reference's scores are complete when
+ * attention/score.py:36-65 returns).  With a workspace of at least THREE times kvz_score_workspace_bytes() the asynchronous log entry
+ * points (kvz_score_chunk_async_log, kvz_update_score_async_log) leave the bounds phase of a call to the next call on the same
+ * workspace and side stream, and its candidate-key phase to the call after that: one launch behind the row-statistics kernel runs the
+ * three phases of three consecutive calls side by side.  The log scores of a call are therefore complete only after two further calls
+ * on its workspace - or after kvz_score_tail_flush(ws), which launches what is pending on the stream those calls used (returns 1 when
+ * something was launched, 0 when nothing was pending, a negative KVZ_E* code on error).  kvz_score_tail_flush_async does the same and
+ * then records the done-event of `slot` on `side`, so that kvz_async_wait(handle, slot | -1, stream) covers the flushed phases.
+ * Until then the caller keeps q, k and the workspace of the pending calls alive and unchanged (the ctx rows of k and all of q are
+ * read again by the candidate-key phase).  Smaller workspaces, other knob values and the synchronous entry points never defer. */
+int kvz_score_tail_flush(const void* ws);
+int kvz_score_tail_flush_async(int handle, int slot, const void* ws, kvz_stream_t side);
 
 /* ------------------------------------------------------------------------- *
  * a4  global-threshold selection     reference: attention/score.py:88-102

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVZIP_HIP_LIB", os.path.join(_HERE, "libkvzip_hip.so"))  # override: A/B builds
 
 KVZ_F16, KVZ_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/kvzip_hip.h (+ the test hooks of include/kvzip_hip_debug.h) one to one
 _vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
@@ -36,6 +36,8 @@ SIGNATURES = {
                                        _sz]),
     "kvz_update_score_async_log": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i64, _i, _i, _i,
                                         _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz]),
+    "kvz_score_tail_flush": (_i, [_vp]),
+    "kvz_score_tail_flush_async": (_i, [_i, _i, _vp, _vp]),
     "kvz_score_from_stats_log": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
     "kvz_score_from_stats_async_log": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64]),
     "kvz_flash_fwd_window": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i64, _i64, _i64, _i, _i, _i, _vp,

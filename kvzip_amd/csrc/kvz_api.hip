@@ -101,12 +101,14 @@ static const char* const g_tune_name[TUNE_COUNT] = {"attn_items", "flash_min_row
 // sel_blocks / emit_blocks: 1024-thread blocks of the histogram passes / of the mask pass of the global-threshold selection (default 0 =
 //   one per CU, device_cus(): every block costs a histogram flush or a prologue, profiles/r4_select.txt).
 // NOTE: debug / measurement hooks - process-wide, set them while no other thread is launching (tests and tools/ only).
-// score_prune (both dtypes, deferred-log entry points, chunks of >= 32 query positions; everything else takes the two full passes whatever the knob says): 3 (default) = key-per-lane
-//   row statistics + candidate keys per row group + gathered column maxima (kvz_score.hip, round 6); 5 = candidate (group, key block) pairs (round 5); 0 = two full passes over
+// score_prune (both dtypes, deferred-log entry points, chunks of >= 32 query positions; everything else takes the two full passes whatever the knob says): 3 = key-per-lane
+//   row statistics + candidate keys per row group + gathered column maxima (kvz_score.hip, round 6: four launches); 6 (default) = the same kernels, the three small launches of
+//   the asynchronous calls as ONE launch pipelined over the calls of a side stream (score_tail_kernel; synchronous entry points and workspaces below three sets: 3);
+//   5 = candidate (group, key block) pairs (round 5); 0 = two full passes over
 //   Q.K^T; 1 / 4 = check variants (key-per-lane statistics with the full column-maximum pass / every (group, key) item through the candidate pass); 16 + mask: launches left out
 //   (time measurements only).  KVZIP_SCORE_PRUNE presets it.
-static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 3};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
-static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {3}};   // (atomic: a probe may flip a knob while another thread launches)
+static const int g_tune_default[TUNE_COUNT] = {0, 64, 128, 1, 0, 0, 1, 6};   // (0 for attn_items / sel_blocks / emit_blocks: derived from device_cus())
+static std::atomic<int> g_tune[TUNE_COUNT] = {{0}, {64}, {128}, {1}, {0}, {0}, {1}, {6}};   // (atomic: a probe may flip a knob while another thread launches)
 // (KVZIP_SCORE_PRUNE in the environment presets the score_prune knob when the library is loaded: A/B runs of whole programs)
 static const int g_tune_env = [] {
     const char* e = getenv("KVZIP_SCORE_PRUNE");
@@ -278,8 +280,10 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
             return KVZ_ELAUNCH;
         }
     }
-    const int rc = log ? kvz_score_chunk_log(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype,
-                                             reinterpret_cast<uint32_t*>(out), out_head_stride, ws, ws_bytes, side)
+    const int rc = log ? (side != caller ? kvz::score_chunk_log_deferred(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D,
+                                                                         dtype, reinterpret_cast<uint32_t*>(out), out_head_stride, ws, ws_bytes, side)
+                                         : kvz_score_chunk_log(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype,
+                                                               reinterpret_cast<uint32_t*>(out), out_head_stride, ws, ws_bytes, side))
                        : kvz_score_chunk(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, out,
                                          out_head_stride, ws, ws_bytes, side);
     if (rc != KVZ_OK) return rc;
@@ -293,6 +297,22 @@ static int score_chunk_async_impl(int handle, int slot, kvz_stream_t caller, kvz
     return KVZ_OK;
 }
 
+
+// the phases earlier calls left pending on `ws` (pipelined tail), then the done-event of `slot` on `side`: kvz_async_wait covers them
+extern "C" int kvz_score_tail_flush_async(int handle, int slot, const void* ws, kvz_stream_t side) {
+    kvz::AsyncCtx* c = kvz::async_get(handle);
+    KVZ_REQUIRE(c, KVZ_EINVAL, "kvz_score_tail_flush_async: bad handle %d", handle);
+    KVZ_REQUIRE(slot >= 0 && slot < (int)c->pending.size(), KVZ_EINVAL, "kvz_score_tail_flush_async: bad slot %d", slot);
+    const int rc = kvz_score_tail_flush(ws);
+    if (rc <= 0) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (hipEventRecord(c->done[slot], (hipStream_t)side) != hipSuccess) {
+        kvz::set_error("kvz_score_tail_flush_async: hipEventRecord failed");
+        return KVZ_ELAUNCH;
+    }
+    c->pending[slot] = 1;
+    return 1;
+}
 
 // one host call per layer of a scoring pass: append the repeat chunk's K,V to the dense cache on the caller's stream, then score
 extern "C" int kvz_update_score_async_log(int handle, int slot, kvz_stream_t caller, kvz_stream_t side, void* k_cache, void* v_cache,

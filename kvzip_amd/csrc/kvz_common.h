@@ -75,6 +75,12 @@ int tunable(Tunable t);
 // - decode work items, selection passes, the finalize + histogram launch, the dense forward's rounds - all derive from this one number
 int device_cus();
 
+// kvz_score_chunk_log for the asynchronous entry points (kvz_api.hip): may leave phases of the call's tail to the next calls on the same
+// workspace and stream (score_prune = 6, kvz_score.hip: score_tail_kernel)
+int score_chunk_log_deferred(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                             int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out, int64_t log_head_stride, void* ws,
+                             size_t ws_bytes, kvz_stream_t stream);
+
 // exact-reciprocal constant of the scoring rounding chain (kvz_score.hip): half(x * r) == half(x / sqrt(D)) for every 16-bit x, or 0
 float score_exact_reciprocal(int D, int dtype);
 

@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -1335,6 +1336,9 @@ __global__ __launch_bounds__(PB_WAVES * 64, PB_OCC) void score_colmax3_kernel(Sc
 // statistics into n_r and the group bounds, score_bounds2_kernel compacts the candidate pairs, score_colmax_sparse_kernel recomputes them.
 
 // first half of the rounding chain for four logits: x = half(float(half(acc)) * rcp) (FAST) or the division; packed results only
+// (round 6: v_fma_mixlo_f16 / v_fma_mixhi_f16 do the multiplication and the second rounding in one instruction per logit - six instead of
+// eight per four logits, the same bits for all 65 536 inputs - and change nothing in the scoring loop: 836 k vs 840 k tokens/s,
+// profiles/r6_mixlo_ab.txt.  The kernel pays for energy per logit, not for instruction slots.)
 template <typename T, bool FAST>
 __device__ static inline void quad_round(float a0, float a1, float a2, float a3, uint32_t& xa, uint32_t& xb, float c, float rcp) {
     if constexpr (std::is_same<T, _Float16>::value && FAST) {
@@ -2213,8 +2217,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, PA_WAVES / 4) void score_rowstatT2_k
 // One block per (256-row tile, KV head), one thread per row: n_r = -(m_r + log l_r) from the unit's partial statistics (the merge of the
 // column-maximum pass: same expression), -inf for the padding rows of the last tile; (max, min) of n over each 32-row group, (NaN, NaN)
 // for a group with a NaN row.  Block 0 resets the candidate counter.
-__global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
-    const int unit = blockIdx.x;
+__device__ static inline void score_merge_body(const ScoreArgs& a, const int unit) {
     const int rt = a.dh.div(unit), h = unit - rt * a.n_kv_heads;
     const int R = a.G * a.q_len;
     const int r = rt * PA_ROWS + (int)threadIdx.x;
@@ -2245,6 +2248,7 @@ __global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) {
     }
     if (unit == 0 && (int)threadIdx.x < a.n_kv_heads) a.counter[threadIdx.x] = 0;
 }
+__global__ __launch_bounds__(PA_ROWS) void score_merge_kernel(ScoreArgs a) { score_merge_body(a, (int)blockIdx.x); }
 
 // ---- candidate pairs of pass B, compacted (round 5) -----------------------------------------------------------------------------------
 // One block per (KV head, 32-key block).  Its [n_groups][32] slab of u is contiguous (28 KiB at the headline shape): every thread reads 8
@@ -2564,16 +2568,24 @@ __global__ __launch_bounds__(SB_WAVES * 64, NBUF == 1 ? KVZ_SB_OCC1 : 2) void sc
 // takes a group's 32 query rows as the A operand and GATHERS 32 of its candidate keys as the B operand (one key per lane), so one 32x32
 // block of logits serves 32 candidates: ~1.6 blocks per group instead of ~11 pairs, a seventh of the matrix and rounding-chain work.  The
 // logit of a (row, key) pair does not depend on where it sits in an MFMA tile, so the column maxima are the bits of the full pass B.
+struct Bounds3Smem {
+    float part[64][33];
+    float lb8[8][32];
+    float lb[32];
+    uint32_t list[64 * BD2_MAXPASS * 2];   // work items opened by this block: at most two per group (32 keys)
+    int n, base, poison;
+};
 template <typename T>
-__global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a) {
-    const int kb = blockIdx.x, h = blockIdx.y;
+__device__ static inline void score_bounds3_body(const ScoreArgs& a, const int kb, const int h, Bounds3Smem& sm) {
     const int tid = threadIdx.x;
     const int oct = tid & 3, grow = tid >> 2;   // 8 keys [8 oct, 8 oct + 8) of group (pass * 64 + grow)
-    __shared__ float s_part[64][33];
-    __shared__ float s_lb8[8][32];
-    __shared__ float s_lb[32];
-    __shared__ uint32_t s_list[64 * BD2_MAXPASS * 2];   // work items opened by this block: at most two per group (32 keys)
-    __shared__ int s_n, s_base, s_poison;
+    auto& s_part = sm.part;
+    auto& s_lb8 = sm.lb8;
+    auto& s_lb = sm.lb;
+    auto& s_list = sm.list;
+    int& s_n = sm.n;
+    int& s_base = sm.base;
+    int& s_poison = sm.poison;
     if (tid == 0) { s_n = 0; s_poison = 0; }
     __syncthreads();   // (the flags are initialised before any wave touches them below)
     const int ng = a.n_groups;
@@ -2697,6 +2709,11 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
     uint32_t* const eh = a.entries + (int64_t)h * a.nkb * a.n_groups;
     for (int i = tid; i < s_n; i += BD2_THREADS) eh[s_base + i] = s_list[i];
 }
+template <typename T>
+__global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a) {
+    __shared__ Bounds3Smem sm;
+    score_bounds3_body<T>(a, (int)blockIdx.x, (int)blockIdx.y, sm);
+}
 
 // The work items - (KV head, row group, chunk of 32 candidate keys), announced by score_bounds3_kernel in per-head queues - are cut into equal
 // shares, one per wave (the blocks of one XCD take one contiguous eighth, as in the pair-level kernel).  Per item: the group's 32 query rows
@@ -2709,13 +2726,18 @@ constexpr int SK_WAVES = 4;
 #ifndef KVZ_SK_BLOCKS_PER_CU
 #define KVZ_SK_BLOCKS_PER_CU 4
 #endif
+template <int D> struct SkSmem {
+    static constexpr int QG_BYTES = 32 * ScoreCfg<D>::ROW_BYTES;      // the 32 query rows of a group, swizzled like a key tile
+    static constexpr int PB_BYTES = QG_BYTES + 256;                   // + their 32 statistics n_r (written twice: one 64-lane dword DMA)
+    static constexpr int BYTES = SK_WAVES * PB_BYTES;
+};
+// (block bid of nblk: the stand-alone launch passes its own index and grid, the fused tail launch the index inside its candidate-key part)
 template <typename T, int D, bool FAST>
-__global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(ScoreArgs a) {
+__device__ static inline void score_colmax_keys_body(const ScoreArgs& a, const uint32_t bid, const uint32_t nblk, char* const lds) {
     typedef ScoreCfg<D> C;
     typedef typename Mfma32<T>::v8 v8;
-    constexpr int QG_BYTES = 32 * C::ROW_BYTES;      // the 32 query rows of a group, swizzled like a key tile
-    constexpr int PB_BYTES = QG_BYTES + 256;         // + their 32 statistics n_r (written twice: one 64-lane dword DMA)
-    __shared__ __attribute__((aligned(16))) char lds[SK_WAVES * PB_BYTES];
+    constexpr int QG_BYTES = SkSmem<D>::QG_BYTES;
+    constexpr int PB_BYTES = SkSmem<D>::PB_BYTES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -2728,9 +2750,9 @@ __global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(Sco
     };
     int total = 0;
     for (int hh = 0; hh < a.n_kv_heads; ++hh) total += head_count(hh);
-    const int nb8 = (int)gridDim.x >> 3;
-    const int lb = (nb8 > 0 && (gridDim.x & 7u) == 0) ? (int)(blockIdx.x & 7u) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int W = gridDim.x * SK_WAVES, w = lb * SK_WAVES + wave;
+    const int nb8 = (int)nblk >> 3;
+    const int lb = (nb8 > 0 && (nblk & 7u) == 0) ? (int)(bid & 7u) * nb8 + (int)(bid >> 3) : (int)bid;
+    const int W = nblk * SK_WAVES, w = lb * SK_WAVES + wave;
     const int per = (total + W - 1) / W;
     const int lo = w * per, hi = min(total, lo + per);
     if (lo >= hi) return;
@@ -2833,6 +2855,36 @@ __global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(Sco
             }
         }
         b0 += nb;
+    }
+}
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(SK_WAVES * 64, 4) void score_colmax_keys_kernel(ScoreArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[SkSmem<D>::BYTES];
+    score_colmax_keys_body<T, D, FAST>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// ---- the tail of the pruned call as ONE launch, pipelined over the calls of a stream (round 6) ------------------------------------------------
+// merge -> bounds -> candidate keys are three launches that each need the one before it; in the scoring loop a row-statistics block takes
+// a whole CU, so every one of them waits for the moment some other stream's row-statistics kernel retires blocks, and the CUs they occupy
+// meanwhile start their next row-statistics block late (8-10 us of an 84-us call).  The phases of DIFFERENT calls do not depend on each
+// other: the launch behind the row-statistics kernel of call i of a stream runs the merge of call i, the bounds of call i-1 and the
+// candidate-key pass of call i-2 of that stream side by side (each call on its own third of the workspace, order by the stream alone, no
+// synchronisation inside the launch) - one burst of short blocks per call instead of three.  The host keeps the arguments of the last two
+// calls per workspace (TailState) and flushes them when the scores are read (kvz_score_tail_flush).
+template <typename T, int D, bool FAST>
+__global__ __launch_bounds__(256, 4) void score_tail_kernel(ScoreArgs am, ScoreArgs ab, ScoreArgs ak, int n_keys, int n_bounds) {
+    static_assert(SK_WAVES * 64 == 256 && BD2_THREADS == 256 && PA_ROWS == 256, "the three phases share one block size");
+    constexpr int BYTES = SkSmem<D>::BYTES > (int)sizeof(Bounds3Smem) ? SkSmem<D>::BYTES : (int)sizeof(Bounds3Smem);
+    __shared__ __attribute__((aligned(16))) char lds[BYTES];
+    const int b = blockIdx.x;   // (wave-uniform branches: a block belongs to one phase)
+    if (b < n_keys) {
+        score_colmax_keys_body<T, D, FAST>(ak, (uint32_t)b, (uint32_t)n_keys, lds);
+    } else if (b < n_keys + n_bounds) {
+        const int v = b - n_keys;
+        const int h = v / ab.nkb;
+        score_bounds3_body<T>(ab, v - h * ab.nkb, h, *reinterpret_cast<Bounds3Smem*>(lds));
+    } else {
+        score_merge_body(am, b - n_keys - n_bounds);
     }
 }
 
@@ -3040,8 +3092,66 @@ static float find_exact_reciprocal_search(float c, int dtype) {
     return found;
 }
 
+// ---- host state of the pipelined tail (score_tail_kernel; knob score_prune = 6) -------------------------------------------------------------
+// Per workspace (= per side stream of a cache object): the arguments of the call whose bounds phase and of the call whose candidate-key
+// phase are still to run, and which third of the workspace the next call takes.  Everything is ordered by the ONE stream the calls of a
+// workspace are launched on.
+struct TailState {
+    ScoreArgs bounds_a, keys_a;
+    bool need_bounds = false, need_keys = false;
+    int code = -1;          // (dtype, head dim, chain variant) of the pending calls: the fused launch is one template instance
+    int next_set = 0;
+    hipStream_t stream = nullptr;
+};
+static std::mutex g_tail_mu;
+static std::map<const void*, TailState> g_tail;
+static inline int tail_code(int dtype, int D, bool fast) { return (dtype == KVZ_BF16 ? 4 : 0) + (D == 128 ? 2 : 0) + (fast ? 1 : 0); }
+
+// one tail launch on st.stream: the merge of `am` (null: none), the bounds of st.bounds_a, the candidate keys of st.keys_a; the state moves on
 template <typename T, int D, bool FAST>
-static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
+static int launch_tail(const ScoreArgs* am, TailState& st) {
+    const ScoreArgs zero{};
+    const int n_keys = st.need_keys ? KVZ_SK_BLOCKS_PER_CU * device_cus() : 0;
+    const int n_bounds = st.need_bounds ? st.bounds_a.nkb * st.bounds_a.n_kv_heads : 0;
+    const int n_merge = am ? (am->G * am->q_len + PA_ROWS - 1) / PA_ROWS * am->n_kv_heads : 0;
+    if (n_keys + n_bounds + n_merge > 0) {
+        ProfScope ps("score_tail", st.stream);
+        hipLaunchKernelGGL((score_tail_kernel<T, D, FAST>), dim3(n_keys + n_bounds + n_merge), dim3(256), 0, st.stream, am ? *am : zero,
+                           st.need_bounds ? st.bounds_a : zero, st.need_keys ? st.keys_a : zero, n_keys, n_bounds);
+        KVZ_CHECK_LAUNCH("score_tail_kernel");
+    }
+    st.keys_a = st.bounds_a;
+    st.need_keys = st.need_bounds;
+    st.need_bounds = am != nullptr;
+    if (am) st.bounds_a = *am;
+    return KVZ_OK;
+}
+// the pending phases of a workspace, to the end (two launches at most)
+static int tail_flush_locked(TailState& st) {
+    while (st.need_bounds || st.need_keys) {
+        int rc;
+        switch (st.code) {
+            case 0: rc = launch_tail<_Float16, 64, false>(nullptr, st); break;
+            case 1: rc = launch_tail<_Float16, 64, true>(nullptr, st); break;
+            case 2: rc = launch_tail<_Float16, 128, false>(nullptr, st); break;
+            case 3: rc = launch_tail<_Float16, 128, true>(nullptr, st); break;
+            case 4: rc = launch_tail<__bf16, 64, false>(nullptr, st); break;
+            case 5: rc = launch_tail<__bf16, 64, true>(nullptr, st); break;
+            case 6: rc = launch_tail<__bf16, 128, false>(nullptr, st); break;
+            case 7: rc = launch_tail<__bf16, 128, true>(nullptr, st); break;
+            default: set_error("kvz_score_tail_flush: corrupt state"); return KVZ_EINVAL;
+        }
+        if (rc != KVZ_OK) return rc;
+    }
+    return KVZ_OK;
+}
+// can this call shape take the pruned call at all?  (launch_score_impl applies the same test)
+static inline bool prune_shape_ok(int n_groups, int nkb, int Hkv, int q_len) {
+    return n_groups <= 64 * BD2_MAXPASS && nkb < 16384 && Hkv < 128 && q_len >= 32;
+}
+
+template <typename T, int D, bool FAST>
+static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream, TailState* tail) {
     a.n_kv_heads = Hkv;
     PaPlan plan;
     if (!get_plan(plan, a.sink, a.m, a.q_len, a.G, Hkv)) {
@@ -3055,13 +3165,22 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     // exact pruning of pass B (round 5; knob score_prune: 0 = two full passes; 1 = key-per-lane pass A, every block of pass B (checks);
     // 3 = candidate pairs only; 4 = every pair through the sparse kernel (checks)).  Both dtypes (round 6); deferred-log path.
     int prune = 0;
-    if (a.unit_nseg && a.n_groups <= 64 * BD2_MAXPASS && a.nkb < 16384 && Hkv < 128 && a.q_len >= 32) prune = tunable(TUNE_SCORE_PRUNE);
+    if (a.unit_nseg && prune_shape_ok(a.n_groups, a.nkb, Hkv, a.q_len)) prune = tunable(TUNE_SCORE_PRUNE);
     if (prune >= 3 && !a.log_out) prune = 1;   // (the sparse pass merges through the log buffer)
+    if (tail && prune != 6) {
+        set_error("kvz_score_chunk: internal - a pipelined tail without the knob");
+        return KVZ_EINVAL;
+    }
+    if (prune == 6 && !tail) prune = 3;        // (6 = 3 with the tail pipelined over the calls of a stream: asynchronous entry points only)
     if (prune) {
         {
             ProfScope ps("score_rowstat", stream);
             hipLaunchKernelGGL((score_rowstatT2_kernel<T, D, FAST>), dim3(plan.nb), dim3(PA_WAVES * 64), 0, stream, a, plan);
             KVZ_CHECK_LAUNCH("score_rowstatT2_kernel");
+        }
+        if (prune == 6) {
+            a.all_pairs = 0;
+            return launch_tail<T, D, FAST>(&a, *tail);
         }
         if (prune >= 3) {
             a.all_pairs = (prune == 4);
@@ -3116,8 +3235,8 @@ static int launch_score_impl(ScoreArgs a, int Hkv, hipStream_t stream) {
     return KVZ_OK;
 }
 template <typename T, int D>
-static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream) {
-    return a.rcp != 0.f ? launch_score_impl<T, D, true>(a, Hkv, stream) : launch_score_impl<T, D, false>(a, Hkv, stream);
+static int launch_score(ScoreArgs a, int Hkv, hipStream_t stream, TailState* tail) {
+    return a.rcp != 0.f ? launch_score_impl<T, D, true>(a, Hkv, stream, tail) : launch_score_impl<T, D, false>(a, Hkv, stream, tail);
 }
 
 }  // namespace kvz
@@ -3163,7 +3282,7 @@ extern "C" size_t kvz_score_workspace_bytes(int Hkv, int G, int q_len, int m, in
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0);
+                            kvz_stream_t stream_, const float* merged_stats = nullptr, int64_t merged_stride = 0, bool defer = false);
 
 extern "C" int kvz_score_chunk(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                                int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
@@ -3235,7 +3354,7 @@ extern "C" int kvz_score_finalize_log_hist(const uint32_t* log, int64_t n, void*
 static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen,
                             int sink, int start, int end, int q_len, int Hkv, int G, int D, int dtype, void* out,
                             int64_t out_head_stride, uint32_t* log_out, int64_t log_head_stride, void* ws, size_t ws_bytes,
-                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride) {
+                            kvz_stream_t stream_, const float* merged_stats, int64_t merged_stride, bool defer) {
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(q && k && (out || log_out) && (ws || merged_stats), KVZ_EINVAL, "kvz_score_chunk: null pointer");
     KVZ_REQUIRE(Hkv > 0 && Hkv <= 65535 && G > 0 && q_len > 0, KVZ_EINVAL, "kvz_score_chunk: bad shape");
@@ -3251,6 +3370,36 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
                 "kvz_score_chunk: a KV head (and the query heads of its group) must span less than 2 GiB");
     KVZ_REQUIRE(merged_stats || ws_bytes >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink), KVZ_EWORKSPACE,
                 "kvz_score_chunk: workspace too small");
+    // pipelined tail (score_prune = 6, asynchronous log entry points, a workspace of three sets): this call takes the next third of the
+    // workspace; phases another call left pending on this workspace run first when this call cannot continue their pipeline
+    TailState* tail = nullptr;
+    std::unique_lock<std::mutex> tail_lock(g_tail_mu, std::defer_lock);
+    if (ws && !merged_stats) {
+        tail_lock.lock();
+        const size_t third = (ws_bytes / 3) & ~(size_t)255;
+        const int code = tail_code(dtype, D, find_exact_reciprocal(D, dtype) != 0.f);
+        const bool want = defer && log_out && tunable(TUNE_SCORE_PRUNE) == 6 && third >= kvz_score_workspace_bytes(Hkv, G, q_len, m, sink) &&
+                          prune_shape_ok(score_n_groups(G, q_len), (m + 31) / 32, Hkv, q_len);
+        auto it = g_tail.find(ws);
+        if (it != g_tail.end() && (it->second.need_bounds || it->second.need_keys) &&
+            (!want || it->second.code != code || it->second.stream != stream)) {
+            TailState& st = it->second;
+            const int rc = tail_flush_locked(st);
+            if (rc != KVZ_OK) return rc;
+            // (another stream takes the workspace over: rare - a rebuilt stream pool - and not worth an event)
+            if (st.stream != stream) KVZ_REQUIRE(hipStreamSynchronize(st.stream) == hipSuccess, KVZ_ELAUNCH, "kvz_score_chunk: hipStreamSynchronize failed");
+        }
+        if (want) {
+            TailState& st = (it != g_tail.end()) ? it->second : g_tail[ws];
+            st.code = code;
+            st.stream = stream;
+            ws = reinterpret_cast<char*>(ws) + (size_t)st.next_set * third;
+            st.next_set = (st.next_set + 1) % 3;
+            tail = &st;
+        } else {
+            tail_lock.unlock();
+        }
+    }
     ScoreArgs a{};
     a.q = q; a.k = k; a.q_head_stride = q_head_stride; a.k_head_stride = k_head_stride;
     a.klen = klen; a.sink = sink; a.start = start; a.m = m; a.q_len = q_len; a.G = G;
@@ -3286,11 +3435,33 @@ static int score_chunk_impl(const void* q, int64_t q_head_stride, const void* k,
     a.c = sqrtf((float)D);  // == float32(math.sqrt(D)) for D in {64, 128}
     a.rcp = find_exact_reciprocal(D, dtype);
     if (dtype == KVZ_F16) {
-        if (D == 128) return launch_score<_Float16, 128>(a, Hkv, stream);
-        return launch_score<_Float16, 64>(a, Hkv, stream);
+        if (D == 128) return launch_score<_Float16, 128>(a, Hkv, stream, tail);
+        return launch_score<_Float16, 64>(a, Hkv, stream, tail);
     }
-    if (D == 128) return launch_score<__bf16, 128>(a, Hkv, stream);
-    return launch_score<__bf16, 64>(a, Hkv, stream);
+    if (D == 128) return launch_score<__bf16, 128>(a, Hkv, stream, tail);
+    return launch_score<__bf16, 64>(a, Hkv, stream, tail);
+}
+
+// the log entry point of the asynchronous calls (kvz_api.hip): the same call, allowed to leave phases of its tail to the next calls on
+// this workspace and stream (score_prune = 6)
+namespace kvz {
+int score_chunk_log_deferred(const void* q, int64_t q_head_stride, const void* k, int64_t k_head_stride, int klen, int sink, int start,
+                             int end, int q_len, int Hkv, int G, int D, int dtype, uint32_t* log_out, int64_t log_head_stride, void* ws,
+                             size_t ws_bytes, kvz_stream_t stream_) {
+    KVZ_REQUIRE(log_out && (reinterpret_cast<uintptr_t>(log_out) & 3u) == 0, KVZ_EINVAL, "kvz_score_chunk_log: bad log buffer");
+    return score_chunk_impl(q, q_head_stride, k, k_head_stride, klen, sink, start, end, q_len, Hkv, G, D, dtype, nullptr, 0, log_out,
+                            log_head_stride, ws, ws_bytes, stream_, nullptr, 0, true);
+}
+}  // namespace kvz
+
+// Runs what earlier calls on this workspace left pending (on the stream they were launched on).  Returns 1 when something was launched,
+// 0 when nothing was pending.  The log scores of a workspace's calls are complete behind this on its stream.
+extern "C" int kvz_score_tail_flush(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    auto it = g_tail.find(ws);
+    if (it == g_tail.end() || !(it->second.need_bounds || it->second.need_keys)) return 0;
+    const int rc = tail_flush_locked(it->second);
+    return rc != KVZ_OK ? rc : 1;
 }
 
 // test hook: the rounding chain on raw 16-bit patterns (exhaustive-check of the exact-reciprocal path on the device)
@@ -3310,6 +3481,13 @@ __global__ void chain_probe_kernel(const uint16_t* in, int n, float c, float rcp
         out[i] = (uint16_t)(xa & 0xffffu);
         return;
     }
+    if (path == 2 || path == 3) {   // the pruned call's chain (quad_round), low / high half of a pair
+        uint32_t xa, xb;
+        if (path == 2) quad_round<T, FAST>((float)x, 1.f, 2.f, 3.f, xa, xb, c, rcp);
+        else quad_round<T, FAST>(1.f, (float)x, 2.f, 3.f, xa, xb, c, rcp);
+        out[i] = (uint16_t)(path == 2 ? (xa & 0xffffu) : (xa >> 16));
+        return;
+    }
     const float r = round_chain<T, FAST>((float)x, c, rcp);
     const T h = (T)r;
     __builtin_memcpy(&b, &h, 2);
@@ -3320,8 +3498,9 @@ extern "C" int kvz_debug_round_chain(const void* in_bits, int n, int D, int dtyp
                                      float* rcp_used, kvz_stream_t stream_) {
     // force_division: 0 = exact-reciprocal multiply (round_chain), 1 = IEEE division, 2 = the reciprocal through the kernels' own
     // four-logit chain (quad_args: for fp16 the assembly block)
-    const int path = force_division == 2 ? 1 : 0;
-    if (force_division == 2) force_division = 0;
+    // 3 / 4: the same through the pruned call's chain (quad_round), low / high half of a pair
+    const int path = force_division >= 2 ? force_division - 1 : 0;
+    if (force_division >= 2) force_division = 0;
     hipStream_t stream = (hipStream_t)stream_;
     KVZ_REQUIRE(in_bits && out_bits && n > 0, KVZ_EINVAL, "kvz_debug_round_chain: bad arguments");
     const float c = sqrtf((float)D);

@@ -128,6 +128,7 @@ class KVScore:
         self._score_log: Optional[torch.Tensor] = None   # [L, 1, Hkv, N] int32: bit patterns of the fp32 log-scores (-inf = empty)
         self._log_dirty = False
         self._dev_idx: Optional[int] = None   # index of the ONE device this object works on (resolved at the first scoring call)
+        self._q_hold = {}              # side-stream slot -> query tensors of the calls whose tail phases are still pending (pipelined tail)
         self._win_stats: List[Optional[torch.Tensor]] = []  # per layer: row statistics written by the scoring forward (f2)
         self.fuse_forward_score = False       # set by the forward pass this package owns (kvzip_amd.attn via ModelKVzip.scoring)
 
@@ -161,11 +162,27 @@ class KVScore:
             lib = ops._lib.load()
             dev = torch.device(self.device)
             idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if layer_idx is None:
+                self._flush_tails(lib)
             ops.check(lib.kvz_async_wait(self._async, -1 if layer_idx is None else layer_idx, ops.raw_stream(idx)), "kvz_async_wait")
             if layer_idx is None:
                 self._pending = False
         if layer_idx is None and finalize and self._log_dirty:
             self._finalize_log()
+
+    def _flush_tails(self, lib):
+        """Pipelined tail of the scoring calls (knob ``score_prune`` = 6): the library leaves the bounds / candidate-key phases of a call to
+        the next two calls on the same workspace and side stream; before anybody reads the scores (or frees what those phases read) the
+        pending phases of every workspace are launched and the done-event of one layer of that stream is recorded behind them
+        (``kvz_score_tail_flush_async``), so the ``kvz_async_wait`` that follows covers them.  A wait for ONE layer (the append of its next
+        chunk) does not need this: it only orders behind the row-statistics kernel that read the repeat rows."""
+        for slot, ws in enumerate(self._score_ws):
+            if ws is None or slot >= len(self._score_side) or slot >= self.n_layers:
+                continue
+            rc = lib.kvz_score_tail_flush_async(self._async, slot, ws.data_ptr(), self._score_side[slot].cuda_stream)
+            if rc < 0:
+                ops.check(rc, "kvz_score_tail_flush_async")
+        self._q_hold = {}   # (freed behind the flush launches: record_stream covers them)
 
     def _finalize_log(self, hist: Optional[torch.Tensor] = None) -> bool:
         """Log buffer -> 16-bit scores (one launch for all layers and chunks).  ``hist``: a selection workspace that receives the
@@ -202,6 +219,13 @@ class KVScore:
             self._release_async()
 
     def _release_async(self):
+        try:   # (nothing may stay pending on a workspace that is about to be freed: its address may come back)
+            lib = ops._lib.load()
+            for ws in self._score_ws:
+                if ws is not None:
+                    lib.kvz_score_tail_flush(ws.data_ptr())
+        except Exception:
+            pass
         if self._async >= 0:
             try:
                 ops._lib.load().kvz_async_destroy(self._async)
@@ -282,6 +306,10 @@ class KVScore:
             need = self._ws_need[(q_len, m, H)] = lib.kvz_score_workspace_bytes(Hkv, H // Hkv, q_len, m, self.sink)
         nstreams = 1 if self._score_exclusive else self._auto_streams(lib, query_states.dtype)
         slot = layer_idx % nstreams if nstreams > 1 else 0
+        # pipelined tail (knob score_prune = 6): three workspace sets per side stream, the library rotates through them
+        pipelined = lib.kvz_debug_get_tunable(b"score_prune") == 6
+        if pipelined:
+            need = 3 * ((need + 255) // 256 * 256)
         while len(self._score_ws) <= slot:
             self._score_ws.append(None)
         ws = self._score_ws[slot]
@@ -305,6 +333,13 @@ class KVScore:
             query_states.record_stream(st)  # a temporary of the forward pass must outlive the side stream's use
             # (key_states is a view of the cache storage, which is only reallocated after _wait_score)
             self._pending = True
+            if pipelined:
+                # the candidate-key phase of this call reads the query rows again two calls later on this stream: the tensor stays
+                # referenced until then (three per stream), or until the tails are flushed
+                hold = self._q_hold.setdefault(slot, [])
+                hold.append(query_states)
+                if len(hold) > 3:
+                    del hold[0]
         n_tot = buf.shape[-1]
         log = self._score_log
         pend = getattr(self, "_pend_app", None)

@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from kvzip_amd import _lib
     lib = _lib.load()
-    assert lib.kvz_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.kvz_abi_version() == _lib.ABI_VERSION == 6
     assert lib.kvz_select_workspace_bytes() >= (2048 + 32) * 4
     assert lib.kvz_compact_plan_bytes(28, 4, 131104) == 28 * 4 * 129 * 4
     assert lib.kvz_score_workspace_bytes(4, 7, 2026, 2000, 32) >= 4 * 7 * 2026 * 8 + 4 * 2000 * 4

@@ -972,7 +972,7 @@ def test_round_chain_exhaustive(dtype, D):
     x = bits.view(dtype)
     want = (x / math.sqrt(D))
     finite = torch.isfinite(x.float())
-    for force_div in (0, 1, 2):   # 2: the reciprocal through the kernels' own four-logit chain (fp16: the assembly block of quad_args)
+    for force_div in (0, 1, 2, 3, 4):   # 2: the reciprocal through the four-logit chain of the two-pass kernels (quad_args); 3 / 4: the pruned call's (quad_round), low / high half
         out = torch.empty(65536, dtype=torch.int16, device=DEV)
         rcp = C.c_float(0)
         rc = lib.kvz_debug_round_chain(bits.to(DEV).data_ptr(), 65536, D, 0 if dtype == torch.float16 else 1, force_div,

@@ -1,4 +1,4 @@
-"""The exact-pruning variant of the scoring call (round 5; round 6: both dtypes, candidates at key granularity; knob ``score_prune``: 3 = the default,
+"""The exact-pruning variant of the scoring call (round 5; round 6: both dtypes, candidates at key granularity; knob ``score_prune``: 3 = the chained call (6, the default, pipelines its three small launches over the calls of a stream: tests/test_gpu_tail_pipeline.py),
 0 = the two-pass call, 5 = round 5's candidate pairs): a key-per-lane pass A that also writes per-group maxima, merged statistics + group bounds, per
 row group the list of ctx keys whose column maximum the group can hold, a pass that recomputes 32 gathered candidate keys per MFMA tile.
 
