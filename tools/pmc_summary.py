@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
         with open(path) as f:
             for row in csv.DictReader(f):
                 name = row.get("Kernel_Name", "")
-                m = re.search(r"(score_rowstatT2|score_colmax_sparse|score_colmax_keys|score_merge|score_bounds2|score_bounds3|score_rowstat\d*|score_colmax\d*|flash2?_fwd|varlen_attn_split\d*|varlen_attn_combine\d*|compact_gather\w*|dense_append|score_finalize\w*)", name)
+                m = re.search(r"(score_rowstatT2|score_tail|score_colmax_sparse|score_colmax_keys|score_merge|score_bounds2|score_bounds3|score_rowstat\d*|score_colmax\d*|flash2?_fwd|varlen_attn_split\d*|varlen_attn_combine\d*|compact_gather\w*|dense_append|score_finalize\w*)", name)
                 if not m:
                     continue
                 key = (m.group(1), row["Counter_Name"])

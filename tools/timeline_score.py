@@ -5,7 +5,7 @@ sits between the end of one and the start of the next, and which small launches 
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 def short(n):
-    for k in ("score_rowstatT2", "score_rowstat2", "score_merge", "score_bounds2", "score_bounds3", "score_colmax_sparse", "score_colmax_keys", "score_colmax3", "dense_append", "finalize"):
+    for k in ("score_rowstatT2", "score_rowstat2", "score_tail", "score_merge", "score_bounds2", "score_bounds3", "score_colmax_sparse", "score_colmax_keys", "score_colmax3", "dense_append", "finalize"):
         if k in n: return k
     return n.split("(")[0][-28:]
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows), key=lambda x: x[0])
