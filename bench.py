@@ -65,6 +65,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-unfused", action="store_true", help="decode with update / prepare / attend as three calls")
     ap.add_argument("--q-pool", type=int, default=0, help="distinct chunk inputs kept in HBM (0 = all chunks)")
+    ap.add_argument("--inputs", default="gauss", choices=["gauss", "copy"],
+                    help="gauss (default, the headline): independent Gaussian q / k; copy: repeat-prompt-like - the query (and the re-read key) of position i of "
+                         "a chunk resembles the context key of that position, so the softmax rows are peaked as in KVzip's own scoring pass "
+                         "(model/wrapper.py:223-249 feeds the context back as a repeat prompt); needs --q-pool 0")
     ap.add_argument("--prof-calls", type=int, default=8,
                     help="the first n scoring calls of every timed step run alone on the caller's stream with their kernels "
                          "bracketed by hipEvents (kernel durations for the roofline; the GPU is idle at a step's start, nothing is "
@@ -226,6 +230,10 @@ def cpu_baseline(args, L, H, Hkv, D, dtype, dev, head_scores):
             klen = sink + off + m + q_len
             qf = torch.randn(1, H, q_len, D, generator=g)
             kf = torch.randn(1, Hkv, klen, D, generator=g)
+            if args.inputs == "copy":   # (the workload's own kind of inputs: queries and re-read keys resemble the chunk's context keys)
+                kc = kf[:, :, sink + off:sink + off + m]
+                qf[:, :, :m] = qf[:, :, :m] * 0.5 + kc.repeat_interleave(H // Hkv, dim=1) * 1.5
+                kf[:, :, klen - q_len:klen - q_len + m] = kf[:, :, klen - q_len:klen - q_len + m] * 0.3 + kc
             q, k = qf.to(dtype), kf.to(dtype)
             t0 = time.perf_counter()
             want = orc.get_score(q, k, sink, sink + off, sink + off + m)
@@ -416,6 +424,13 @@ def _run(args):
             Qs.append(randn(L, 1, H, q_max, D))
             Ks.append(randn(L, 1, Hkv, q_max, D))
             Vs.append(randn(L, 1, Hkv, q_max, D))
+        if args.inputs == "copy":
+            assert pool == len(chunks), "--inputs copy: every chunk needs its own inputs (--q-pool 0)"
+            for c, (st, en, q_len) in enumerate(chunks):
+                for l in range(L):
+                    kc = store_k[l][:, :, st:en]                                  # [1, Hkv, m, D]: the context keys of this chunk
+                    Qs[c][l][:, :, :en - st] = (Qs[c][l][:, :, :en - st].float() * 0.5 + kc.repeat_interleave(H // Hkv, dim=1).float() * 1.5).to(dtype)
+                    Ks[c][l][:, :, :en - st] = (Ks[c][l][:, :, :en - st].float() * 0.3 + kc.float()).to(dtype)
     cfg = types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hkv)
     # per (input set, query length) the per-layer views handed to the cache object: what a forward pass would hand over as
     # ready tensors; slicing them inside the timed loop would charge ~15 us of harness indexing to every (layer, chunk)
@@ -756,7 +771,7 @@ def _run(args):
         "metric": metric, "value": world * N * args.steps / elapsed, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "ms_per_step_per_rank": per_rank_ms,   # every rank's own steps (no barrier): comparable with the N = 1 line
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.inputs == "gauss" else "synthetic (repeat-prompt-like: --inputs copy)",
         "config": {
             "workload": workload, "level": args.level,
             "ratio": ratio, "real_ratio": r_real, "threshold": thres, "kept_rows": int(kept_rows),
