@@ -2723,9 +2723,6 @@ __global__ __launch_bounds__(BD2_THREADS) void score_bounds3_kernel(ScoreArgs a)
 // merged, one atomic minimum per key on the log-score patterns (the merge of the dense pass).  The next item's candidate indices are
 // requested while the current one is computed.
 constexpr int SK_WAVES = 4;
-#ifndef KVZ_SK_ABL
-#define KVZ_SK_ABL 0   // (1 / 2: time-attribution builds of the candidate-key pass, results unusable - tools/r6_ab12.sh)
-#endif
 #ifndef KVZ_SK_BLOCKS_PER_CU
 #define KVZ_SK_BLOCKS_PER_CU 4
 #endif
@@ -2759,9 +2756,6 @@ __device__ static inline void score_colmax_keys_body(const ScoreArgs& a, const u
     const int per = (total + W - 1) / W;
     const int lo = w * per, hi = min(total, lo + per);
     if (lo >= hi) return;
-#if KVZ_SK_ABL == 1
-    return;   // (time attribution only: blocks that load the counters and leave)
-#endif
     const int64_t head_cap = (int64_t)a.nkb * ng;
     const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     char* const wl = lds + wave * PB_BYTES;
@@ -2799,12 +2793,6 @@ __device__ static inline void score_colmax_keys_body(const ScoreArgs& a, const u
             const int g = (int)(e & 2047u), h = (int)(e >> 25);
             const uint32_t j = j_next;
             const int nv = nv_next;
-#if KVZ_SK_ABL == 2
-            // (time attribution only: queue entry and candidate list loaded, nothing computed)
-            if (i + 1 < nb) j_next = cand(entry(i + 1), nv_next);
-            if (half == 0 && l31 < nv && j == 0xFFFFFFFFu) atomicMin(a.log_out + (int64_t)h * a.log_head_stride + g, 1u);
-            continue;
-#endif
             {   // rows and statistics of group g -> the wave's LDS buffer (nothing through registers)
                 const char* qh = reinterpret_cast<const char*>(a.q) + (int64_t)h * a.G * hs;
                 const int rc0 = min(g * 32, R - 1);
@@ -3120,11 +3108,17 @@ static std::map<const void*, TailState> g_tail;
 static inline int tail_code(int dtype, int D, bool fast) { return (dtype == KVZ_BF16 ? 4 : 0) + (D == 128 ? 2 : 0) + (fast ? 1 : 0); }
 
 // one tail launch on st.stream: the merge of `am` (null: none), the bounds of st.bounds_a, the candidate keys of st.keys_a; the state moves on
+// candidate-key blocks of the tail launch: one per CU.  In the burst of short blocks that a tail launch is, 1 024 blocks (what the stand-alone launch
+// uses) cost 3 % of the scoring loop against 256; 128 / 64 / 32 gain another 0.5 % on Gaussian inputs and lose 5 % on repeat-prompt-like ones (more
+// candidates per group): profiles/r6_tail_blocks_ab.txt
+#ifndef KVZ_SK_TAIL_BLOCKS
+#define KVZ_SK_TAIL_BLOCKS device_cus()
+#endif
 template <typename T, int D, bool FAST>
 static int launch_tail(const ScoreArgs* am, TailState& st) {
     const ScoreArgs zero{};
-    const int n_keys = (st.need_keys && KVZ_SK_ABL < 3) ? KVZ_SK_BLOCKS_PER_CU * device_cus() : 0;   // (KVZ_SK_ABL 3 / 4: time attribution, phases left out)
-    const int n_bounds = (st.need_bounds && KVZ_SK_ABL < 4) ? st.bounds_a.nkb * st.bounds_a.n_kv_heads : 0;
+    const int n_keys = st.need_keys ? KVZ_SK_TAIL_BLOCKS : 0;
+    const int n_bounds = st.need_bounds ? st.bounds_a.nkb * st.bounds_a.n_kv_heads : 0;   // (two / four key blocks per block: -6 % / -14 % in the loop, profiles/r6_tail_blocks_ab.txt)
     const int n_merge = am ? (am->G * am->q_len + PA_ROWS - 1) / PA_ROWS * am->n_kv_heads : 0;
     if (n_keys + n_bounds + n_merge > 0) {
         ProfScope ps("score_tail", st.stream);

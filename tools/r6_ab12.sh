@@ -1,4 +1,5 @@
 #!/bin/bash
+# (time-attribution builds: apply tools/attic/abl_keys_r6.patch to kvzip_amd/csrc first, then tools/ab_build.sh skablN -DKVZ_SK_ABL=N)
 # round 6 (second session): where the time of the candidate-key phase goes IN THE LOOP (pipelined tail; time-attribution builds, results unusable):
 # product / skabl2: queue entry + candidate list loaded, nothing computed / skabl1: blocks load the counters and leave / skabl3: no candidate-key blocks / skabl4: no bounds blocks either
 O=gpurun_out/r6u; mkdir -p $O
