@@ -2876,7 +2876,7 @@ __global__ __launch_bounds__(256, 4) void score_tail_kernel(ScoreArgs am, ScoreA
     static_assert(SK_WAVES * 64 == 256 && BD2_THREADS == 256 && PA_ROWS == 256, "the three phases share one block size");
     constexpr int BYTES = SkSmem<D>::BYTES > (int)sizeof(Bounds3Smem) ? SkSmem<D>::BYTES : (int)sizeof(Bounds3Smem);
     __shared__ __attribute__((aligned(16))) char lds[BYTES];
-    const int b = blockIdx.x;   // (wave-uniform branches: a block belongs to one phase)
+    const int b = blockIdx.x;   // (wave-uniform branches: a block belongs to one phase; bounds first or merge first: no difference, profiles/r6_tail_blocks_ab.txt)
     if (b < n_keys) {
         score_colmax_keys_body<T, D, FAST>(ak, (uint32_t)b, (uint32_t)n_keys, lds);
     } else if (b < n_keys + n_bounds) {
@@ -3119,7 +3119,7 @@ static int launch_tail(const ScoreArgs* am, TailState& st) {
     const ScoreArgs zero{};
     const int n_keys = st.need_keys ? KVZ_SK_TAIL_BLOCKS : 0;
     const int n_bounds = st.need_bounds ? st.bounds_a.nkb * st.bounds_a.n_kv_heads : 0;   // (two / four key blocks per block: -6 % / -14 % in the loop, profiles/r6_tail_blocks_ab.txt)
-    const int n_merge = am ? (am->G * am->q_len + PA_ROWS - 1) / PA_ROWS * am->n_kv_heads : 0;
+    const int n_merge = am ? (am->G * am->q_len + PA_ROWS - 1) / PA_ROWS * am->n_kv_heads : 0;   // (as its own launch - its blocks fit beside row-statistics blocks - +0.3 %, +4 us of host time: not worth the launch)
     if (n_keys + n_bounds + n_merge > 0) {
         ProfScope ps("score_tail", st.stream);
         hipLaunchKernelGGL((score_tail_kernel<T, D, FAST>), dim3(n_keys + n_bounds + n_merge), dim3(256), 0, st.stream, am ? *am : zero,
