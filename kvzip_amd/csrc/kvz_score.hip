@@ -3465,9 +3465,13 @@ int score_chunk_log_deferred(const void* q, int64_t q_head_stride, const void* k
 extern "C" int kvz_score_tail_flush(const void* ws) {
     std::lock_guard<std::mutex> lk(g_tail_mu);
     auto it = g_tail.find(ws);
-    if (it == g_tail.end() || !(it->second.need_bounds || it->second.need_keys)) return 0;
-    const int rc = tail_flush_locked(it->second);
-    return rc != KVZ_OK ? rc : 1;
+    if (it == g_tail.end()) return 0;
+    const bool pending = it->second.need_bounds || it->second.need_keys;
+    const int rc = pending ? tail_flush_locked(it->second) : KVZ_OK;
+    // a drained workspace is forgotten: nothing of it is referenced any more, and an address that comes back (a freed workspace, another
+    // cache object) starts from a clean state instead of inheriting this one's stream and set counter
+    if (rc == KVZ_OK) g_tail.erase(it);
+    return rc != KVZ_OK ? rc : (pending ? 1 : 0);
 }
 
 // test hook: the rounding chain on raw 16-bit patterns (exhaustive-check of the exact-reciprocal path on the device)
